@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/ref_harness, built by
+`make -C oracle`).  Every fixture = inputs + the reference's outputs for them; nothing here
+is reference source.  The reference ships no tests and no golden files of its own,
+so these vectors are the pin for oracle/weld_oracle.c (tests/test_oracle_golden.py) and,
+through it, for the HIP path.
+
+    python3 tests/golden/make_golden.py            # regenerate everything (~2 min)
+
+Also copies the two binary STL *data* files the configs name (cubic.stl 684 B,
+simplified_piece.stl 299 KB) so that the GPU box -- which has no /root/reference -- can run
+BASELINE configs C1/C2.
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+import waf  # noqa: E402
+
+REFROOT = "/root/reference"
+TMP = "/tmp/weld_golden"
+os.makedirs(TMP, exist_ok=True)
+
+
+def keep(d, keys):
+    return {k: d[k] for k in keys if k in d}
+
+
+def pack_free(d):
+    d = dict(d)
+    d["free_packed"] = np.packbits(d.pop("free"))
+    return d
+
+
+ACS_KEYS = ["dims", "precision", "start_id", "end_id", "points_ok", "best_L", "best_path", "best_choice",
+            "colony_last", "lambda_last", "Q_last", "rand_calls", "next_rand", "pher_sum", "pher_hash",
+            "tr_colony", "tr_finite", "tr_steps", "tr_bestL", "tr_iterbestL", "tr_lambda", "tr_Q"]
+
+
+def main():
+    assert O.have_ref(), "build oracle/_ref first: make -C oracle"
+    for f in ("cubic.stl", "simplified_piece.stl"):
+        shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))
+        os.chmod(os.path.join(HERE, f), 0o644)
+    cubic = os.path.join(HERE, "cubic.stl")
+    piece = os.path.join(HERE, "simplified_piece.stl")
+
+    # ---- libc / libstdc++ known answers ------------------------------------------------
+    r = O.run_ref("rand", TMP + "/rand.waf", seed=12345, n=64)
+    waf.save(HERE + "/rand_12345.waf", r)
+    sorts = {}
+    for i, (n, lv, sd) in enumerate([(16, 3, 1), (17, 2, 2), (64, 4, 3), (256, 8, 4), (257, 1, 5), (1000, 50, 6)]):
+        s = O.run_ref("sort", TMP + "/sort.waf", n=n, levels=lv, seed=sd)
+        sorts["keys%d" % i] = s["keys"]
+        sorts["perm%d" % i] = s["perm"]
+    waf.save(HERE + "/std_sort.waf", sorts)
+
+    # ---- voxelisation (KA1) ---------------------------------------------------------------
+    for tag, stl, p, wall in [("cubic_p0219_w8", cubic, "0.0219", 8), ("cubic_p0225_w8", cubic, "0.0225", 8),
+                              ("piece_p0148_w4", piece, "0.0148", 4)]:
+        v = O.run_ref("voxelize", TMP + "/v.waf", stl=stl, p=p, wall=wall)
+        v = pack_free(v)
+        if v["tris"].size > 12 * 16:
+            v["tris_head"] = v["tris"][:12 * 16].copy()
+            v["tris_sum"] = np.array([np.sum(v["tris"].astype(np.float64))])
+            del v["tris"]
+        v.pop("t_voxelize", None)
+        waf.save(HERE + "/vox_%s.waf" % tag, v)
+
+    # ---- ACS_Rank (KA2 and friends) -------------------------------------------------------
+    cases = [
+        ("acs_cubic_ka2_native", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=50, predict="1.03")),
+        ("acs_cubic_ka2_driven", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=50, predict="1.03", driven=1)),
+        ("acs_cubic_predict5", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=150, predict="5", driven=1)),
+        ("acs_cubic_fixed16", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=777, iters=50, predict="1.03", fixed=16)),
+        ("acs_cubic_seam", dict(stl=cubic, p="0.0225", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=10, predict="1.03", driven=1)),
+        ("acs_piece_adaptive", dict(stl=piece, p="0.0148", wall=4, snode="0,0,0", enode="22,32,63", seed=12345, iters=200, predict="5.4126", driven=1)),
+        ("acs_piece_fixed128", dict(stl=piece, p="0.0148", wall=4, snode="0,0,0", enode="22,32,63", seed=12345, iters=200, predict="5.4126", fixed=128)),
+    ]
+    for tag, kw in cases:
+        a = O.run_ref("acs", TMP + "/a.waf", **kw)
+        out = keep(a, ACS_KEYS)
+        out["args"] = np.frombuffer(repr(sorted((k, str(v) if k != "stl" else os.path.basename(v)) for k, v in kw.items())).encode(), np.uint8)
+        waf.save(HERE + "/%s.waf" % tag, out)
+        print(tag, a["best_L"], len(a["best_path"]))
+
+    # ---- synthetic 128^3 (KA3-style, our own PRNG) -------------------------------------------
+    g = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    gin = TMP + "/synth128.in"
+    O.write_grid_in(g, gin)
+    for tag, kw in [("acs_synth128_adaptive10", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=10, predict="731.43", driven=1)),
+                    ("acs_synth128_fixed256_4", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=4, predict="731.43", fixed=256))]:
+        a = O.run_ref("acs", TMP + "/a.waf", **kw)
+        out = keep(a, ACS_KEYS)
+        out["args"] = np.frombuffer(repr(sorted((k, str(v)) for k, v in kw.items() if k != "gridin")).encode(), np.uint8)
+        out["grid_seed"] = np.array([2024], np.int64)
+        out["grid_free_count"] = np.array([int(g.free.sum())], np.int64)
+        out["grid_fnv"] = np.array([O.fnv1a_bytes(g.free.tobytes()) - (1 << 64) if O.fnv1a_bytes(g.free.tobytes()) >= (1 << 63) else O.fnv1a_bytes(g.free.tobytes())], np.int64)
+        waf.save(HERE + "/%s.waf" % tag, out)
+        print(tag, a["best_L"], a["tr_colony"], a["tr_steps"])
+
+    # ---- pair flow + GTSP on cubic (main.cpp:279-283) --------------------------------------------
+    vg = O.run_ref("voxelize", TMP + "/v.waf", stl=cubic, p="0.0219", wall=8)
+    cx, cy, cz = vg["cx"], vg["cy"], vg["cz"]
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12)]
+    pts = TMP + "/cubic_weld_points.in"
+    with open(pts, "w") as f:
+        f.write("%d\n" % len(nodes))
+        for z, y, x in nodes:
+            f.write("%f %f %f\n" % (cx[x], cy[y], cz[z]))
+    shutil.copyfile(pts, HERE + "/cubic_weld_points.in")
+    pr = O.run_ref("pairs", TMP + "/p.waf", stl=cubic, p="0.0219", wall=8, pts=pts, predict="0.5", seed=4321,
+                   graph=TMP + "/graph.in", gtsp=1)
+    waf.save(HERE + "/pairs_cubic.waf", pr)
+    print("pairs", pr["pair_cost"].reshape(5, 5), waf.text(pr, "graph_text")[:40].encode(), pr["tour_edges"], pr["tour_L"], pr["gtsp_iters"])
+
+    # ---- GTSP alone (KA4) ----------------------------------------------------------------------
+    def write_graph(path, n, fn):
+        with open(path, "w") as f:
+            f.write("%d %d\n" % (n, n * (n - 1) // 2))
+            for i in range(n):
+                for j in range(i + 1, n):
+                    f.write("%s\n" % fn(i, j))
+    write_graph(TMP + "/g8.in", 8, lambda i, j: "%.1f" % (((7 * i + 13 * j) % 10 + 1) / 10.0))
+    g8 = O.run_ref("gtsp", TMP + "/g8.waf", graph=TMP + "/g8.in", seed=1)
+    g8.pop("t_gtsp", None)
+    waf.save(HERE + "/gtsp_ka4_n8.waf", g8)
+    print("gtsp8", g8["tour_L"], g8["gtsp_iters"], g8["tour_edges"][::2] + 1)
+    st = np.uint64(4242)
+    rs = np.random.RandomState(4242)
+    P = rs.randint(0, 100, size=(64, 3))
+    write_graph(TMP + "/g64.in", 64, lambda i, j: "%.3f" % (np.abs(P[i] - P[j]).sum() / 100.0 + 0.001))
+    g64 = O.run_ref("gtsp", TMP + "/g64.waf", graph=TMP + "/g64.in", seed=4242)
+    g64.pop("t_gtsp", None)
+    waf.save(HERE + "/gtsp_n64.waf", g64)
+    print("gtsp64", g64["tour_L"], g64["gtsp_iters"])
+
+
+if __name__ == "__main__":
+    main()
