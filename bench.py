@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- ACS generations/sec on the BASELINE workload (config C3 per GPU; C4 across GPUs).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE ACS generation (walk + rank + evaporate + ranked deposit, ACSRank_3D.hpp:237-299)
+of the 128^3 / 256-ant search.  Every rank owns an independent 128^3 random-obstacle grid (weak
+scaling, no data-path collective); for N > 1 the per-generation global-best cost is MIN
+all-reduced over RCCL in chunks of generations, overlapped with the next chunk.  W warm-up
+generations run on a throw-away search; then EXACTLY K generations of a fresh search are timed
+between barrier + synchronize pairs, inputs already resident in HBM (the per-problem setup --
+pheromone init, heuristic field -- is outside the timed region and reported as setup_ms).
+
+Rank 0 prints one JSON line: metric/value (whole-job generations/s), `roofline` for the
+evaporation sweep (HIP events on the library's own stream, sampled inside the timed region),
+and -- at N = 1 -- `cpu_baseline`: the reference's own loop (oracle/_ref/ref_harness, kind
+"reference") or the C oracle (kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GRID_N, ANTS, CHUNK = 128, 256, 50
+PREDICT = 731.43  # = 256 ants * precision / 0.35 (ACSRank_3D.hpp:247); only scales Q until a first path exists
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--grid", type=int, default=GRID_N)
+    ap.add_argument("--ants", type=int, default=ANTS)
+    ap.add_argument("--cpu-gens", type=int, default=20, help="generations of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
+    """Reported baseline (never the target).  Same grid, same parameters, first `cpu_gens`
+    generations (the longest walks of the run); 1 thread like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O  # cpu_baseline leg only
+    G = args.cpu_gens
+    og = O.Grid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), free, 1.0, 0)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, n - 1, np.float32))
+    out = {}
+    # cost check: the DEV-mode port draws the same numbers as the GPU, so best cost must be equal
+    a = O.Acs(og)
+    t0 = time.time()
+    tr = a.solve(sid, eid, G, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=12345, stream=0)
+    t_port = time.time() - t0
+    port_rate = G / t_port
+    cost_equal = bool(np.array_equal(tr["bestL"].view(np.uint32), gpu_trace["bestL"][:G].view(np.uint32)))
+    out["cost_check"] = {"generations": G, "cpu_best_cost": float(tr["bestL"][-1]), "gpu_best_cost": float(gpu_trace["bestL"][G - 1]),
+                         "bit_equal_trace": cost_equal}
+    sample = "generations 0..%d of the same %d^3 / %d-ant search (the run's longest walks); GPU took %.2f ms for the same window" % (
+        G - 1, n, args.ants, gpu_first_ms)
+    if O.have_ref():
+        tmp = "/tmp/weld_bench_%d" % os.getpid()
+        os.makedirs(tmp, exist_ok=True)
+        O.write_grid_in(og, tmp + "/grid.in")
+        p = subprocess.run([O.REF_BIN, "acs", "gridin=%s/grid.in" % tmp, "spt=0,0,0", "ept=%d,%d,%d" % (n - 1, n - 1, n - 1),
+                            "seed=12345", "iters=%d" % G, "predict=%s" % PREDICT, "fixed=%d" % args.ants, "out=%s/o.waf" % tmp],
+                           stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+        line = [l for l in p.stderr.splitlines() if l.startswith("{")]
+        if p.returncode == 0 and line:
+            j = json.loads(line[-1])
+            out["cpu_baseline"] = {"value": G / j["t_solve"], "unit": "generations/s", "cores": 1, "kind": "reference",
+                                   "sample": sample + "; reference phase split walk %.0f%% evaporate %.0f%% deposit %.0f%%" % (
+                                       100 * j["t_walk"] / j["t_solve"], 100 * j["t_evap"] / j["t_solve"], 100 * j["t_dep"] / j["t_solve"]),
+                                   "init_s": j["t_init"], "port_value": port_rate}
+            return out
+    out["cpu_baseline"] = {"value": port_rate, "unit": "generations/s", "cores": 1, "kind": "port", "sample": sample}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: relaunch under torchrun as a CHILD process (never exec after GPU init)
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from welding_robot_amd import api, synth
+    from welding_robot_amd import dist as wd
+
+    rank, local_rank, world = wd.env_rank()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    ctx = api.Context(local_rank)  # raises if libweldacs.so or the device is missing: no fallback
+    n, K, W = args.grid, args.steps, args.warmup
+    wl = wd.per_rank_workload(rank)
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=wl["grid_seed"], occ_prob=0.10)
+    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    ids = grid.resolve(np.array([[0, 0, 0], [n - 1, n - 1, n - 1]], np.float32))
+    solver = api.AcsSolver(ctx, grid, n_slots=1, max_colony=args.ants)
+
+    def params(iters, seed):
+        return api.default_params(max_iteration=iters, predict=PREDICT, fixed_colony=args.ants, rng_mode=api.RNG_DEV, seed=seed)
+
+    # ---- warm-up: W generations of a throw-away search (different key), untimed
+    if W > 0:
+        solver.init_pheromone(1.0)
+        solver.begin(params(W, wl["rng_seed"] + 1000), ids[0], ids[1], streams=[wl["stream"]])
+        solver.run(W)
+        solver.sync()
+    # ---- per-problem setup, untimed (reported)
+    t_setup = time.perf_counter()
+    solver.init_pheromone(1.0)
+    solver.begin(params(K, wl["rng_seed"]), ids[0], ids[1], streams=[wl["stream"]])
+    ctx.sync()
+    setup_ms = (time.perf_counter() - t_setup) * 1e3
+    solver.profile(True, args.profile_every)
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev) if world > 1 else None
+    chunk = min(CHUNK, K)
+    gbuf = [torch.empty(chunk, dtype=torch.float32, device=dev) for _ in range((K + chunk - 1) // chunk)] if world > 1 else []
+    works = []
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    done = 0
+    while done < K:
+        c = min(chunk, K - done)
+        solver.run(c)
+        if world > 1:  # global-best cost of generations done..done+c-1, MIN over ranks, async on RCCL
+            gb = gbuf[done // chunk]
+            solver.export_trace(gb.data_ptr(), done, c)
+            with torch.cuda.stream(ext):
+                works.append(wd.allreduce_min_(gb[:c], async_op=True))
+        done += c
+    solver.sync()
+    for w in works:
+        if w is not None:
+            w.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = wd.max_over_ranks(elapsed, dev)
+    total_gens = wd.sum_over_ranks(K, dev)
+
+    prof = solver.profile_read()
+    cost, path, _ = solver.result()
+    trace = solver.trace()
+    best_all = wd.max_over_ranks(-float(cost), dev) * -1.0  # min over ranks
+    if rank == 0:
+        ev = prof["evaporate"]
+        evap_ms = ev["ms"] / max(ev["launches"], 1)
+        alg_bytes = 48.0 * n ** 3  # 6 fp32 read + written per voxel
+        achieved = alg_bytes / (evap_ms * 1e-3) / 1e9 if evap_ms > 0 else 0.0
+        out = {
+            "metric": "acs_generations_per_sec", "value": wd.aggregate_rate(total_gens, elapsed), "unit": "generations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3 per GPU: %d^3 synthetic random-obstacle grid (10%% occupied, splitmix64 seed 2024+rank), "
+                                   "%d ants fixed, %d generations, alpha 1 beta 0.6 rho 0.8, DEV rng seed 12345+rank; "
+                                   "one independent problem per GPU (C4)" % (n, args.ants, K),
+                       "grid": [n, n, n], "ants": args.ants, "generations": K, "problems_per_gpu": 1,
+                       "global_best_allreduce": "MIN over ranks per generation, chunks of %d" % chunk if world > 1 else "n/a (1 GPU)"},
+            "roofline": {"bound": "hbm", "kernel": "k_evaporate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": evap_ms, "sampled_launches": ev["launches"],
+                         "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
+            "setup_ms": setup_ms, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
+            "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
+            "device": ctx.device_name,
+        }
+        if world == 1 and not args.no_cpu:
+            G = min(args.cpu_gens, K)
+            # GPU time for the same first-G window, measured on a fresh identical search
+            solver.profile(False, 1)
+            solver.init_pheromone(1.0)
+            solver.begin(params(K, wl["rng_seed"]), ids[0], ids[1], streams=[wl["stream"]])
+            ctx.sync()
+            t1 = time.perf_counter()
+            solver.run(G)
+            solver.sync()
+            gpu_first_ms = (time.perf_counter() - t1) * 1e3
+            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

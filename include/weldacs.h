@@ -1,0 +1,169 @@
+/* include/weldacs.h -- C ABI of libweldacs.so (MI355X / gfx950 HIP backend).
+ *
+ * The reference (mhsitu/welding_robot) has no FFI: its planning path lives behind the public
+ * members of header-only C++ classes.  This header is the boundary a maintainer
+ * binds instead; each entry point names the reference interface it replaces.  The drop-in C++
+ * headers under welding_robot_amd/include/core/ (same class names as the reference) are written
+ * purely on top of this ABI, and tests/bench reach it through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-allocated outputs, opaque handles.
+ *   - every function returns a wa_status (0 = ok) unless it returns a count; wa_last_error()
+ *     gives the text.  The library never exit()s and never prints (the reference does both:
+ *     read_STL.hpp:34-59, ACSRank_3D.hpp:239).
+ *   - there is NO CPU fallback: with no HIP device wa_ctx_create fails with WA_ERR_DEVICE.
+ *   - lattice: voxel id = (z*ny + y)*nx + x  (model_grid_map.hpp:203-216);
+ *     edge k of a voxel: 0:z-1 1:y-1 2:x-1 3:x+1 4:y+1 5:z+1  (ACSRank_3D.hpp:355-365).
+ *   - a wa_ctx and everything created from it is used from one host thread at a time.
+ */
+#ifndef WELDACS_H
+#define WELDACS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    WA_OK = 0,
+    WA_ERR_ARG = 1,       /* bad argument / null pointer / size                          */
+    WA_ERR_DEVICE = 2,    /* no HIP device, HIP runtime error                            */
+    WA_ERR_ALLOC = 3,     /* host or device allocation failed                            */
+    WA_ERR_FILE = 4,      /* cannot open / short read (read_STL.hpp:34-59 exit(1..3))    */
+    WA_ERR_FORMAT = 5,    /* malformed STL / unsupported ASCII STL          */
+    WA_ERR_POINT = 6,     /* a route point resolves to no free voxel (ACSRank_3D.hpp:491) */
+    WA_ERR_CAPACITY = 7,  /* a walk outgrew path_capacity / more ants than max_colony     */
+    WA_ERR_STATE = 8      /* call order (e.g. results before a solve)                     */
+} wa_status;
+
+typedef struct wa_ctx wa_ctx;
+typedef struct wa_grid wa_grid;
+typedef struct wa_acs wa_acs;
+
+/* ---- context --------------------------------------------------------------------------- */
+const char *wa_version(void);
+int wa_ctx_create(int device_ordinal, wa_ctx **out);
+void wa_ctx_destroy(wa_ctx *ctx);
+const char *wa_last_error(const wa_ctx *ctx);
+int wa_ctx_device_name(const wa_ctx *ctx, char *buf, size_t cap);
+int wa_ctx_sync(wa_ctx *ctx);
+/* the HIP stream every kernel of this context is launched on (hipStream_t as void*) */
+void *wa_ctx_stream(wa_ctx *ctx);
+
+/* ---- mesh input: replaces STLReader::readFile + TriangleList (read_STL.hpp:26-77,:88,:131-156)
+ * tris = n x 12 floats (normal, v0, v1, v2).  Returns the triangle count (>= 0) or -wa_status.
+ * Pass tris = NULL to query the count. */
+int64_t wa_stl_parse(const void *buf, size_t len, float *tris, int64_t cap_tris);
+int64_t wa_stl_read_file(const char *path, float *tris, int64_t cap_tris);
+
+/* ---- grid map: replaces GridMap<float>::creatGridMap / readGridMap / ptr_grid_map
+ *      (model_grid_map.hpp:151-298, :300-356, :358) -------------------------------------- */
+/* voxelise a mesh on the device (bbox :165-181, ranges :198-200, coords :204-211, occupancy
+ * :223-268).  bbox6_out (optional) = min xyz, max xyz of the mesh. */
+int wa_grid_from_mesh(wa_ctx *ctx, const float *tris, int64_t n_tris, float precision, int32_t wall,
+                      wa_grid **out, float *bbox6_out);
+/* adopt an existing occupancy (free_[id] != 0 <=> isFree) with per-axis node coordinates --
+ * the readGridMap path and the synthetic benchmark grids */
+int wa_grid_from_occupancy(wa_ctx *ctx, const uint8_t *free_, int32_t nx, int32_t ny, int32_t nz,
+                           const float *cx, const float *cy, const float *cz, float precision,
+                           int32_t wall, wa_grid **out);
+/* model_grid_map.hpp:204-211 / :321-328 piecewise axis coordinates (host helper, n values) */
+int wa_axis_coords(float lo, float hi, float precision, int32_t wall, int32_t n, float *out);
+void wa_grid_destroy(wa_grid *g);
+int wa_grid_info(const wa_grid *g, int32_t dims3[3], float *precision, int32_t *wall, int64_t *n_free);
+int wa_grid_read_occupancy(const wa_grid *g, uint8_t *free_out /* nx*ny*nz */);
+int wa_grid_read_coords(const wa_grid *g, float *cx, float *cy, float *cz);
+/* ACS_Rank::setPoints / checkRoutePoints (ACSRank_3D.hpp:537-565, :511-535): for each point the
+ * LAST free voxel in raster order within +-(float)(1.2*precision) on every axis; -1 if none. */
+int wa_grid_resolve_points(const wa_grid *g, const float *pts_xyz, int32_t n_pts, int64_t *ids_out);
+
+/* ---- rank-based ACS: replaces ACS_Rank::initFromGridMap / computeSolution / reset /
+ *      searchBestPathOfPoints' pair loop / getSolution (ACSRank_3D.hpp:220-504) ----------- */
+enum { WA_RNG_REF = 0, WA_RNG_DEV = 1 };
+/* WA_RNG_REF: glibc rand() stream shared sequentially by all ants and all problems, libstdc++
+ *             std::sort tie order -- bit-identical to the reference, ants walk one after another
+ *             (a parity mode, one wavefront per problem).
+ * WA_RNG_DEV: counter-based draw keyed (seed, stream, generation, ant, step), ranks ties by ant
+ *             index -- the parallel production mode, one wavefront per ant. */
+typedef struct {
+    int32_t alpha;          /* pheromone exponent, reference 1       (ACSRank_3D.hpp:319) */
+    float beta;             /* heuristic weight, reference 0.6       (:320)               */
+    float rho;              /* evaporation factor, reference 0.8     (:321)               */
+    float pheromone_0;      /* reference 1                           (:324)               */
+    int32_t max_iteration;  /* generations, reference 150            (:322)               */
+    float predict;          /* computeSolution(predict_path_len)     (:220)               */
+    int32_t fixed_colony;   /* 0: reference-adaptive colony (:247); >0: pinned ant count   */
+    int32_t rng_mode;       /* WA_RNG_REF / WA_RNG_DEV                                     */
+    uint64_t seed;          /* DEV counter key (REF: use wa_acs_srand)                     */
+} wa_acs_params;
+void wa_acs_default_params(wa_acs_params *p);
+
+/* n_slots independent problems can be in flight (each owns a pheromone field: 24 B/voxel, a
+ * heuristic field: 24 B/voxel, a deposit mask: 48 B/voxel).  max_colony bounds the ants per
+ * generation, path_capacity the nodes per walk (<= number of voxels). */
+int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                  int64_t path_capacity, wa_acs **out);
+void wa_acs_destroy(wa_acs *s);
+/* initFromGridMap :343-408: in-bounds edges pheromone_0, out-of-bounds edges 0. slot<0: all */
+int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float pheromone_0);
+/* reset() :307-315: every edge pheromone_0 */
+int wa_acs_reset_pheromone(wa_acs *s, int32_t slot, float pheromone_0);
+/* REF mode libc state: srand(seed) (:327); get/set = 34 words + 2 indices, to hand the stream
+ * on to wa_gtsp_solve exactly as the reference's process-global rand() does */
+int wa_acs_srand(wa_acs *s, uint32_t seed);
+int wa_acs_rand_state(wa_acs *s, int32_t state36_inout[36], int32_t set);
+
+/* start n_problems searches on slots 0..n-1 (setPoints already resolved to voxel ids; streams[i]
+ * is the DEV-mode stream key of problem i, NULL = 0..n-1), then advance all of them by
+ * n_generations (enqueued on the context stream, asynchronous), then wait. */
+int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const int64_t *start_ids,
+                 const int64_t *end_ids, const uint32_t *streams);
+int wa_acs_run(wa_acs *s, int32_t n_generations);
+int wa_acs_sync(wa_acs *s);
+/* begin + run(max_iteration) + sync */
+int wa_acs_solve(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const int64_t *start_ids,
+                 const int64_t *end_ids, const uint32_t *streams);
+
+/* best-so-far of a slot (Agent<float> best: L, path ids, edge choices = nodeIndex()).  When no
+ * ant has arrived cost = +inf (a valid result) and len = 0. */
+int wa_acs_result(wa_acs *s, int32_t slot, float *cost, int64_t *len, int32_t *path_ids,
+                  int8_t *choices, int64_t cap);
+/* per-generation history the reference computes and discards (:295-296).  Arrays of
+ * generations_done entries; any pointer may be NULL. */
+int wa_acs_trace(wa_acs *s, int32_t slot, int32_t *generations_done, float *best_L, float *iter_best_L,
+                 int32_t *colony, int32_t *finite, int64_t *steps);
+/* device-to-device copy (on the context stream) of best_L[gen0 .. gen0+count) of every active
+ * slot into dst_device[slot*count + g] -- feeds the RCCL MIN all-reduce of the global best */
+int wa_acs_export_trace(wa_acs *s, void *dst_device, int32_t gen0, int32_t count);
+int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out /* nvox*6 */);
+int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, float *Q);
+
+/* kernel timing with HIP events on the context stream.  Enable before wa_acs_run; afterwards
+ * ms[i]/launches[i] hold the summed event time and launch count of kernel class i. */
+enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_COUNT = 4 };
+int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
+int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
+/* evaporation sweep alone (ACSRank_3D.hpp:268-272) over `slot` -- for roofline measurements */
+int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats);
+
+/* ---- weld-seam ordering: replaces ACS_GTSP::readFromGraphFile's init + computeSolution
+ *      (ACS_GTSP.hpp:187-218, :224-253, :255-284) ----------------------------------------- */
+typedef struct {
+    int32_t rng_mode;        /* WA_RNG_REF / WA_RNG_DEV */
+    uint64_t seed;           /* DEV */
+    uint32_t stream;         /* DEV */
+    int32_t max_iterations;  /* <= 0: city_num^2 (:216) */
+} wa_gtsp_params;
+/* dist = n x n row-major symmetric doubles (diagonal ignored), cnt = distance count of the graph
+ * header (:229).  n_instances problems laid out back to back (dist, tour_edges 2*n each, cost,
+ * iters).  REF mode: rand_state36 (inout, may be NULL -> srand(1)) continues the libc stream
+ * and n_instances must be 1. */
+int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32_t n_instances,
+                  const wa_gtsp_params *p, int32_t *rand_state36, int32_t *tour_edges,
+                  double *tour_cost, int32_t *iterations, double *pheromone_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WELDACS_H */

@@ -1,0 +1,101 @@
+"""CPU-side checks of the product boundary: libweldacs.so loads, exports exactly what
+include/weldacs.h declares, refuses to run without a GPU, and its host-only entry points (STL
+parse, axis coordinates) agree with the oracle.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from welding_robot_amd import _lib as L
+from welding_robot_amd import api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        build.build()
+    return L.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "weldacs.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libweldacs.so does not export %s" % name
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+
+
+def test_no_torch_or_cxx_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include", "weldacs.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # declarations only, comments stripped
+    assert "std::" not in code and "torch" not in code and "hipStream_t" not in code and "&" not in code
+
+
+def test_product_never_links_the_oracle():
+    pkg = os.path.join(ROOT, "welding_robot_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                bad = re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|libweld_oracle|oracle_lib|_ref/', txt)
+                assert not bad, (os.path.join(dp, f), bad.group(0))
+
+
+def _has_gpu(lib):
+    h = C.c_void_p()
+    rc = lib.wa_ctx_create(0, C.byref(h))
+    if rc == 0:
+        lib.wa_ctx_destroy(h)
+    return rc == 0
+
+
+def test_fails_loudly_without_device(lib):
+    if _has_gpu(lib):
+        pytest.skip("a HIP device is present")
+    with pytest.raises(api.WeldacsError) as e:
+        api.Context(0)
+    assert e.value.code == 2  # WA_ERR_DEVICE
+
+
+def test_stl_parse_matches_oracle(lib):
+    for f in ("cubic.stl", "simplified_piece.stl"):
+        data = open(os.path.join(G, f), "rb").read()
+        a, b = api.stl_parse(data), O.stl_parse(data)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(api.stl_read_file(os.path.join(G, f)).view(np.uint32), b.view(np.uint32))
+
+
+def test_stl_error_codes(lib):
+    data = bytearray(open(os.path.join(G, "cubic.stl"), "rb").read())
+    with pytest.raises(api.WeldacsError) as e:
+        api.stl_parse(bytes(data[:100]))
+    assert e.value.code == 4  # short read -> the reference exit(3)s (read_STL.hpp:55-59)
+    data[79] = ord("s")
+    with pytest.raises(api.WeldacsError) as e:
+        api.stl_parse(bytes(data))
+    assert e.value.code == 5
+    with pytest.raises(api.WeldacsError) as e:
+        api.stl_read_file("/nonexistent/file.stl")
+    assert e.value.code == 4  # the reference exit(1)s (read_STL.hpp:34-38)
+
+
+def test_axis_coords_match_oracle(lib):
+    for lo, hi, p, wall, n in [(1.61, 1.79, 0.0219, 8, 25), (-0.249, 0.101, 0.0225, 8, 32), (0, 127, 1.0, 0, 128),
+                               (-1, 1, 0.3, 2, 11)]:
+        out = np.empty(n, np.float32)
+        O.lib().wo_axis_coords(C.c_float(lo), C.c_float(hi), C.c_float(p), wall, n, out.ctypes.data)
+        assert np.array_equal(api.axis_coords(lo, hi, p, wall, n).view(np.uint32), out.view(np.uint32))
+
+
+def test_default_params_are_the_reference_literals(lib):
+    p = api.default_params()
+    assert (p.alpha, p.max_iteration) == (1, 150)  # ACSRank_3D.hpp:319,322
+    assert np.float32(p.beta) == np.float32(0.6) and np.float32(p.rho) == np.float32(0.8) and p.pheromone_0 == 1.0

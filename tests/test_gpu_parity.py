@@ -1,0 +1,388 @@
+"""GPU parity tests proper: libweldacs.so (HIP, through the C ABI) against
+  (1) the golden vectors captured from the REAL reference  -- WA_RNG_REF mode, bit-exact;
+  (2) the C oracle on the same seeded inputs                -- WA_RNG_DEV mode, bit-exact;
+  (3) size-independent properties at BASELINE's full sizes.
+Bar: voxel ids / occupancy / ranks bit-exact, fp32 pheromone fields and costs bit-exact
+(stricter than north_star's 1e-6 relative)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import pipeline_ref as PR
+import waf
+from welding_robot_amd import api
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _g(name):
+    return waf.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+_ogrids = {}
+
+
+def ogrid(stl, p, wall):
+    key = (stl, p, wall)
+    if key not in _ogrids:
+        _ogrids[key] = O.grid_from_mesh(O.stl_parse(open(os.path.join(G, stl), "rb").read()), float(p), wall)
+    return _ogrids[key]
+
+
+def dgrid_from(ctx, og):
+    return api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+
+
+def test_device_is_gfx950(ctx):
+    assert "gfx950" in ctx.device_name
+
+
+# ------------------------------------------------------------------ voxelise + resolve (a3, a10)
+@pytest.mark.parametrize("tag,stl,p,wall", [("cubic_p0219_w8", "cubic.stl", "0.0219", 8),
+                                            ("cubic_p0225_w8", "cubic.stl", "0.0225", 8),
+                                            ("piece_p0148_w4", "simplified_piece.stl", "0.0148", 4)])
+def test_voxelize_matches_reference(ctx, tag, stl, p, wall):
+    g = _g("vox_%s.waf" % tag)
+    tris = api.stl_read_file(os.path.join(G, stl))
+    dg = api.Grid.from_mesh(ctx, tris, float(p), wall)
+    assert [dg.nx, dg.ny, dg.nz, dg.wall] == g["dims"].tolist()
+    cx, cy, cz = dg.coords()
+    assert np.array_equal(bits(cx), bits(g["cx"])) and np.array_equal(bits(cy), bits(g["cy"])) and np.array_equal(bits(cz), bits(g["cz"]))
+    occ = dg.occupancy()
+    assert np.array_equal(np.packbits(occ), g["free_packed"])
+    assert dg.n_free == int(occ.sum())
+    if tag == "cubic_p0219_w8":
+        assert O.fnv1a_bytes(occ.tobytes()) == 0x5A60BC32E3EFED2F and dg.n_free == 17732  # KA1
+
+
+def test_voxelize_random_mesh_vs_oracle(ctx):
+    rs = np.random.RandomState(5)
+    tris = np.zeros((40, 12), np.float32)
+    v = rs.uniform(-1, 1, (40, 3, 3)).astype(np.float32)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    tris[:, :3] = n
+    tris[:, 3:] = v.reshape(40, 9)
+    og = O.grid_from_mesh(tris, 0.07, 3)
+    dg = api.Grid.from_mesh(ctx, tris, 0.07, 3)
+    assert (dg.nx, dg.ny, dg.nz) == (og.nx, og.ny, og.nz)
+    assert np.array_equal(dg.occupancy(), og.free)
+
+
+def test_resolve_points_last_match_wins(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    rs = np.random.RandomState(1)
+    pts = [og.node_pt(4, 4, 4), og.node_pt(20, 27, 20), og.node_pt(12, 16, 12), np.array([99, 99, 99], np.float32)]
+    for _ in range(40):
+        z, y, x = rs.randint(0, og.nz), rs.randint(0, og.ny), rs.randint(0, og.nx)
+        pts.append(og.node_pt(z, y, x) + rs.uniform(-0.02, 0.02, 3).astype(np.float32))
+    pts = np.array(pts, np.float32)
+    want = np.array([og.resolve(p) for p in pts])
+    got = dg.resolve(pts)
+    assert np.array_equal(got, want)
+    assert got[0] == 4130 and got[1] == 17521 and got[3] == -1 and (want == -1).sum() >= 2
+    sg = O.synth_grid(128)
+    dsg = dgrid_from(ctx, sg)
+    assert dsg.resolve(np.array([[0, 0, 0], [127, 127, 127]], np.float32)).tolist() == [16513, 2097151]  # Q4
+
+
+# ------------------------------------------------------------------ ACS, REF mode == the reference itself
+def _check_against_golden(ctx, tag, og=None, max_colony=None):
+    g = _g(tag + ".waf")
+    args = dict(ast.literal_eval(waf.text(g, "args")))
+    if og is None:
+        og = ogrid(args["stl"], args["p"], int(args["wall"]))
+    dg = dgrid_from(ctx, og)
+    if "snode" in args:
+        sz, sy, sx = [int(v) for v in args["snode"].split(",")]
+        ez, ey, ex = [int(v) for v in args["enode"].split(",")]
+        pts = np.array([og.node_pt(sz, sy, sx), og.node_pt(ez, ey, ex)])
+    else:
+        pts = np.array([[float(v) for v in args[k].split(",")] for k in ("spt", "ept")], np.float32)
+    ids = dg.resolve(pts)
+    assert ids[0] == waf.scalar(g, "start_id") and ids[1] == waf.scalar(g, "end_id")
+    iters, fixed = int(args["iters"]), int(args.get("fixed", 0))
+    predict = float(np.float32(args["predict"]))
+    bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max(bound, 1))
+    s.srand(int(args["seed"]))
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_REF)
+    s.solve(p, ids[0], ids[1])
+    cost, path, ch = s.result()
+    assert bits(cost) == bits(g["best_L"])
+    assert np.array_equal(path, g["best_path"]) and np.array_equal(ch.astype(np.int32), g["best_choice"])
+    ph = s.pheromone()
+    assert O.pher_hash(ph) == waf.scalar(g, "pher_hash") & ((1 << 64) - 1)
+    st = s.rand_state()
+    rng = O.GlibcRand()
+    for i in range(34):
+        rng.r[i] = int(st[i])
+    rng.f, rng.b = int(st[34]), int(st[35])
+    assert O.rand(rng) == waf.scalar(g, "next_rand")  # the libc stream is exactly where the reference left it
+    c, lam, q = s.last_params()
+    assert c == waf.scalar(g, "colony_last") and bits(lam) == bits(g["lambda_last"]) and bits(q) == bits(g["Q_last"])
+    if "tr_bestL" in g:
+        t = s.trace()
+        assert np.array_equal(bits(t["bestL"]), bits(g["tr_bestL"]))
+        assert np.array_equal(bits(t["iterbestL"]), bits(g["tr_iterbestL"]))
+        assert np.array_equal(t["colony"], g["tr_colony"]) and np.array_equal(t["finite"], g["tr_finite"])
+        assert np.array_equal(t["steps"], g["tr_steps"])
+    s.close()
+    return g
+
+
+@pytest.mark.parametrize("tag", ["acs_cubic_ka2_native", "acs_cubic_ka2_driven", "acs_cubic_predict5",
+                                 "acs_cubic_fixed16", "acs_cubic_seam", "acs_piece_adaptive", "acs_piece_fixed128"])
+def test_acs_ref_mode_equals_reference(ctx, tag):
+    g = _check_against_golden(ctx, tag)
+    if tag == "acs_cubic_seam":
+        assert np.isinf(g["best_L"][0])  # Q3: NaN seam, every ant dies
+
+
+@pytest.mark.parametrize("tag", ["acs_synth128_adaptive10", "acs_synth128_fixed256_4"])
+def test_acs_ref_mode_equals_reference_128cube(ctx, tag):
+    _check_against_golden(ctx, tag, og=O.synth_grid(128, seed=2024, occ_prob=0.10))
+
+
+def test_pair_flow_and_gtsp_ref_mode_equals_reference(ctx):
+    """main.cpp:279-283 through the C ABI, REF mode, against the reference's own run."""
+    g = _g("pairs_cubic.waf")
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    pts = PR.read_points_file(os.path.join(G, "cubic_weld_points.in"))
+    ids = dg.resolve(pts)
+    P = len(pts)
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=int(0.35 * 0.5 / 0.0219) + 1)
+    s.srand(4321)
+    p = api.default_params(max_iteration=150, predict=0.5, rng_mode=api.RNG_REF)
+    cost = np.zeros((P, P), np.float32)
+    paths, order = {}, []
+    for i in range(P):
+        for j in range(i + 1, P):
+            s.solve(p, ids[i], ids[j])
+            s.reset_pheromone(1.0)
+            c, path, _ = s.result()
+            cost[i, j] = cost[j, i] = c
+            paths[(i, j)] = paths[(j, i)] = path
+            order.append(float(c))
+    assert np.array_equal(bits(cost.reshape(-1)), bits(g["pair_cost"]))
+    assert np.array_equal(np.concatenate([paths[(i, j)] for i in range(P) for j in range(i + 1, P)]), g["pair_paths_upper"])
+    assert O.pher_hash(s.pheromone()) == waf.scalar(g, "pher_hash") & ((1 << 64) - 1)
+    graph = PR.graph_file_bytes(P, order)
+    assert graph == g["graph_text"].tobytes()
+    dist, cnt = PR.parse_graph_text(graph.decode())
+    t = api.gtsp_solve(ctx, dist, cnt=cnt, mode=api.RNG_REF, rand_state=s.rand_state())
+    assert t["iters"][0] == waf.scalar(g, "gtsp_iters")
+    assert np.array_equal(t["edges"].reshape(-1), g["tour_edges"]) and t["L"][0] == waf.scalar(g, "tour_L")
+    x, y, z = PR.read_all_segments(og, t["edges"][0], paths)
+    assert np.array_equal(bits(x), bits(g["g_path_x"])) and np.array_equal(bits(z), bits(g["g_path_z"]))
+    rng = O.GlibcRand()
+    for i in range(34):
+        rng.r[i] = int(t["rand_state"][i])
+    rng.f, rng.b = int(t["rand_state"][34]), int(t["rand_state"][35])
+    assert O.rand(rng) == waf.scalar(g, "next_rand")
+
+
+@pytest.mark.parametrize("tag,seed", [("gtsp_ka4_n8", 1), ("gtsp_n64", 4242)])
+def test_gtsp_ref_mode_equals_reference(ctx, tag, seed):
+    g = _g(tag + ".waf")
+    n = int(round(np.sqrt(g["gtsp_dis"].size)))
+    rng = O.srand(seed)
+    st = np.array(list(rng.r) + [rng.f, rng.b], np.int32)
+    t = api.gtsp_solve(ctx, g["gtsp_dis"].reshape(n, n), mode=api.RNG_REF, rand_state=st, want_pher=True)
+    assert t["iters"][0] == waf.scalar(g, "gtsp_iters")
+    assert np.array_equal(t["edges"].reshape(-1), g["tour_edges"])
+    assert t["L"][0] == waf.scalar(g, "tour_L")
+    assert np.array_equal(t["pher"].reshape(-1).view(np.uint64), g["gtsp_pher"].view(np.uint64))
+
+
+# ------------------------------------------------------------------ ACS, DEV mode == C oracle in DEV mode
+def _dev_vs_oracle(ctx, og, sid, eid, iters, predict, fixed, seed, stream=0, max_colony=None, **solver_kw):
+    dg = dgrid_from(ctx, og)
+    bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max_colony or max(bound, 1), **solver_kw)
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_DEV, seed=seed)
+    s.solve(p, sid, eid, streams=[stream])
+    a = O.Acs(og)
+    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream)
+    t = s.trace()
+    assert np.array_equal(t["steps"], tr["steps"]), (t["steps"][:5], tr["steps"][:5])
+    assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))
+    assert np.array_equal(t["colony"], tr["colony"]) and np.array_equal(t["finite"], tr["finite"])
+    cost, path, ch = s.result()
+    ids, och = a.best_path()
+    assert bits(cost) == bits(a.best_L)
+    if np.isfinite(cost):
+        assert np.array_equal(path, ids) and np.array_equal(ch.astype(np.int32), och)
+    assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+    s.close()
+    return t
+
+
+def test_acs_dev_cubic_vs_oracle(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    _dev_vs_oracle(ctx, og, sid, eid, 50, 1.03, 16, seed=12345)
+    _dev_vs_oracle(ctx, og, sid, eid, 150, 5.0, 0, seed=7, stream=3)  # adaptive colony (Q1)
+
+
+def test_acs_dev_seam_vs_oracle(ctx):
+    og = ogrid("cubic.stl", "0.0225", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    t = _dev_vs_oracle(ctx, og, sid, eid, 10, 1.03, 0, seed=1)
+    assert np.all(np.isinf(t["bestL"]))
+
+
+def test_acs_dev_piece_c2_vs_oracle(ctx):
+    """BASELINE config C2: simplified_piece.stl, 64x33x23, 128 ants, 200 iterations."""
+    og = ogrid("simplified_piece.stl", "0.0148", 4)
+    sid, eid = og.resolve(og.node_pt(0, 0, 0)), og.resolve(og.node_pt(og.nz - 1, og.ny - 1, og.nx - 1))
+    assert (sid, eid) == (2177, 48575)
+    _dev_vs_oracle(ctx, og, sid, eid, 200, 5.4126, 128, seed=12345)
+
+
+def test_acs_dev_synth64_vs_oracle(ctx):
+    og = O.synth_grid(64, seed=77, occ_prob=0.15)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 63, np.float32))
+    _dev_vs_oracle(ctx, og, sid, eid, 40, 300.0, 96, seed=99)
+
+
+def test_acs_dev_synth128_c3_first_generations_vs_oracle(ctx):
+    """BASELINE config C3 inputs (128^3, 256 ants); the oracle affords a few generations."""
+    og = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    _dev_vs_oracle(ctx, og, 16513, 2097151, 6, 731.43, 256, seed=12345)
+
+
+def test_tabu_spill_to_global_bitmap_keeps_parity(ctx):
+    """A 64-entry LDS hash forces every walk through the spill path (bitmap tabu)."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    os.environ["WA_HASH_LOG2"] = "6"
+    try:
+        _dev_vs_oracle(ctx, og, sid, eid, 30, 1.03, 16, seed=5)
+        _dev_vs_oracle(ctx, og, sid, eid, 30, 1.03, 16, seed=6)  # second solver: bitmaps were left clean
+    finally:
+        del os.environ["WA_HASH_LOG2"]
+
+
+def test_batch_of_problems_equals_single_runs(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12)]
+    ids = [og.resolve(og.node_pt(*n)) for n in nodes]
+    pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+    p = api.default_params(max_iteration=60, predict=0.5, rng_mode=api.RNG_DEV, seed=2024)
+    sb = api.AcsSolver(ctx, dg, n_slots=len(pairs), max_colony=8)
+    sb.solve(p, [ids[i] for i, _ in pairs], [ids[j] for _, j in pairs], streams=list(range(len(pairs))))
+    for k, (i, j) in enumerate(pairs):
+        a = O.Acs(og)
+        a.solve(ids[i], ids[j], 60, 0.5, mode=O.DEV, seed=2024, stream=k)
+        cost, path, _ = sb.result(k)
+        assert bits(cost) == bits(a.best_L)
+        if np.isfinite(cost):
+            assert np.array_equal(path, a.best_path()[0])
+        assert np.array_equal(bits(sb.pheromone(k)), bits(a.pheromone()))
+
+
+def test_gtsp_dev_vs_oracle(ctx):
+    rs = np.random.RandomState(3)
+    for n in (5, 16, 64):
+        P = rs.uniform(0, 1, (n, 3))
+        d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1)
+        o = O.gtsp_solve(d, mode=O.DEV, seed=11, stream=2, want_pher=True)
+        t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=11, stream=2, want_pher=True)
+        assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"]
+        assert np.array_equal(t["edges"][0], o["edges"])
+        assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64))
+    # batched instances = independent streams
+    d2 = np.stack([d, d[::-1, ::-1].copy()])
+    t2 = api.gtsp_solve(ctx, d2, mode=api.RNG_DEV, seed=11, stream=2)
+    o2 = O.gtsp_solve(d2[1], mode=O.DEV, seed=11, stream=3)
+    assert t2["L"][0] == o["L"] and t2["L"][1] == o2["L"] and np.array_equal(t2["edges"][1], o2["edges"])
+
+
+# ------------------------------------------------------------------ evaporation sweep (Q12 denormals)
+def test_evaporation_keeps_fp32_denormals(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=4)
+    s.init_pheromone(1.0)
+    s.evaporate(0, 0.8, 500)
+    s.sync()
+    v = np.float32(1.0)
+    for _ in range(500):
+        v = np.float32(v * np.float32(0.8))
+    ph = s.pheromone()
+    assert v > 0 and v < np.finfo(np.float32).tiny  # a denormal, not flushed (fixed point 2 ulp)
+    inb = ph != 0
+    assert np.all(bits(ph[inb]) == bits(v)) and inb.sum() > 0
+    assert bits(v) == 2
+
+
+# ------------------------------------------------------------------ full-size properties (C3)
+def test_full_size_c3_properties(ctx):
+    """128^3 / 256 ants / DEV mode at length: path validity, cost = accumulated steps, monotone best,
+    pheromone positivity, and determinism of a re-run (the oracle cannot afford this many steps)."""
+    og = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    dg = dgrid_from(ctx, og)
+    p = api.default_params(max_iteration=120, predict=731.43, fixed_colony=256, rng_mode=api.RNG_DEV, seed=12345)
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=256)
+    s.solve(p, 16513, 2097151)
+    cost, path, ch = s.result()
+    t = s.trace()
+    assert np.isfinite(cost) and path[0] == 16513 and path[-1] == 2097151
+    assert len(np.unique(path)) == len(path) and np.all(og.free[path] == 1)
+    d = np.diff(path.astype(np.int64))
+    nx, nxy = 128, 128 * 128
+    delta = np.array([-nxy, -nx, -1, 1, nx, nxy])
+    assert np.array_equal(d, delta[ch])
+    L = np.float32(0)
+    for _ in range(len(path) - 1):
+        L = np.float32(L + np.float32(1.0))
+    assert bits(cost) == bits(L) and cost >= 378.0  # Manhattan optimum between the two corners
+    fin = t["bestL"][np.isfinite(t["bestL"])]
+    assert np.all(np.diff(fin) <= 0) and bits(t["bestL"][-1]) == bits(cost)
+    assert np.all(t["colony"] == 256) and np.all(t["iterbestL"] >= t["bestL"])
+    ph1 = s.pheromone()
+    assert np.all(ph1 >= 0) and np.all(np.isfinite(ph1))
+    s2 = api.AcsSolver(ctx, dg, n_slots=1, max_colony=256)
+    s2.solve(p, 16513, 2097151)
+    assert np.array_equal(bits(s2.pheromone()), bits(ph1)) and np.array_equal(s2.result()[1], path)
+    assert cost <= 480.0  # the colony has converged towards the optimum by generation 120
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_error_codes(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    s = api.AcsSolver(ctx, dg, n_slots=2, max_colony=8)
+    p = api.default_params(max_iteration=2, predict=0.5, rng_mode=api.RNG_DEV)
+    with pytest.raises(api.WeldacsError) as e:
+        s.solve(p, [4130, -1], [17521, 17521])
+    assert e.value.code == 6  # WA_ERR_POINT: the reference prints "Wrong point" and returns (:491-497)
+    with pytest.raises(api.WeldacsError) as e:
+        s.solve(api.default_params(max_iteration=2, predict=5.0), 4130, 17521)  # 79 ants > max_colony 8
+    assert e.value.code == 7
+    with pytest.raises(api.WeldacsError) as e:
+        s.solve(api.default_params(max_iteration=2, predict=0.5, rng_mode=api.RNG_REF), [4130, 4130], [17521, 17521])
+    assert e.value.code == 1
+    s3 = api.AcsSolver(ctx, dg, n_slots=1, max_colony=8, path_capacity=8)
+    with pytest.raises(api.WeldacsError) as e:
+        s3.solve(p, 4130, 17521)
+    assert e.value.code == 7  # a walk outgrew path_capacity: refused rather than silently inexact

@@ -1,0 +1,92 @@
+"""ctypes loader for libweldacs.so -- the HIP product library.
+
+There is no fallback of any kind: if the shared object is missing this raises, and if the
+process has no HIP device `Context()` raises (wa_ctx_create -> WA_ERR_DEVICE)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libweldacs.so")
+
+WA_OK = 0
+STATUS = {0: "WA_OK", 1: "WA_ERR_ARG", 2: "WA_ERR_DEVICE", 3: "WA_ERR_ALLOC", 4: "WA_ERR_FILE",
+          5: "WA_ERR_FORMAT", 6: "WA_ERR_POINT", 7: "WA_ERR_CAPACITY", 8: "WA_ERR_STATE"}
+RNG_REF, RNG_DEV = 0, 1
+K_WALK, K_RANK, K_EVAPORATE, K_DEPOSIT, K_COUNT = 0, 1, 2, 3, 4
+
+
+class AcsParams(C.Structure):
+    _fields_ = [("alpha", C.c_int32), ("beta", C.c_float), ("rho", C.c_float), ("pheromone_0", C.c_float),
+                ("max_iteration", C.c_int32), ("predict", C.c_float), ("fixed_colony", C.c_int32),
+                ("rng_mode", C.c_int32), ("seed", C.c_uint64)]
+
+
+class GtspParams(C.Structure):
+    _fields_ = [("rng_mode", C.c_int32), ("seed", C.c_uint64), ("stream", C.c_uint32),
+                ("max_iterations", C.c_int32)]
+
+
+# every symbol include/weldacs.h declares: name -> (restype, argtypes)
+_V, _I, _I64, _F, _P = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SYMBOLS = {
+    "wa_version": (C.c_char_p, []),
+    "wa_ctx_create": (C.c_int, [C.c_int, C.POINTER(_V)]),
+    "wa_ctx_destroy": (None, [_V]),
+    "wa_last_error": (C.c_char_p, [_V]),
+    "wa_ctx_device_name": (C.c_int, [_V, C.c_char_p, C.c_size_t]),
+    "wa_ctx_sync": (C.c_int, [_V]),
+    "wa_ctx_stream": (_V, [_V]),
+    "wa_stl_parse": (_I64, [_P, C.c_size_t, _P, _I64]),
+    "wa_stl_read_file": (_I64, [C.c_char_p, _P, _I64]),
+    "wa_grid_from_mesh": (C.c_int, [_V, _P, _I64, _F, _I, C.POINTER(_V), _P]),
+    "wa_grid_from_occupancy": (C.c_int, [_V, _P, _I, _I, _I, _P, _P, _P, _F, _I, C.POINTER(_V)]),
+    "wa_axis_coords": (C.c_int, [_F, _F, _F, _I, _I, _P]),
+    "wa_grid_destroy": (None, [_V]),
+    "wa_grid_info": (C.c_int, [_V, _P, _P, _P, _P]),
+    "wa_grid_read_occupancy": (C.c_int, [_V, _P]),
+    "wa_grid_read_coords": (C.c_int, [_V, _P, _P, _P]),
+    "wa_grid_resolve_points": (C.c_int, [_V, _P, _I, _P]),
+    "wa_acs_default_params": (None, [C.POINTER(AcsParams)]),
+    "wa_acs_create": (C.c_int, [_V, _V, _I, _I, _I64, C.POINTER(_V)]),
+    "wa_acs_destroy": (None, [_V]),
+    "wa_acs_init_pheromone": (C.c_int, [_V, _I, _F]),
+    "wa_acs_reset_pheromone": (C.c_int, [_V, _I, _F]),
+    "wa_acs_srand": (C.c_int, [_V, C.c_uint32]),
+    "wa_acs_rand_state": (C.c_int, [_V, _P, _I]),
+    "wa_acs_begin": (C.c_int, [_V, C.POINTER(AcsParams), _I, _P, _P, _P]),
+    "wa_acs_run": (C.c_int, [_V, _I]),
+    "wa_acs_sync": (C.c_int, [_V]),
+    "wa_acs_solve": (C.c_int, [_V, C.POINTER(AcsParams), _I, _P, _P, _P]),
+    "wa_acs_result": (C.c_int, [_V, _I, _P, _P, _P, _P, _I64]),
+    "wa_acs_trace": (C.c_int, [_V, _I, _P, _P, _P, _P, _P, _P]),
+    "wa_acs_export_trace": (C.c_int, [_V, _V, _I, _I]),
+    "wa_acs_read_pheromone": (C.c_int, [_V, _I, _P]),
+    "wa_acs_last_params": (C.c_int, [_V, _I, _P, _P, _P]),
+    "wa_acs_profile": (C.c_int, [_V, _I, _I]),
+    "wa_acs_profile_read": (C.c_int, [_V, _P, _P]),
+    "wa_acs_evaporate": (C.c_int, [_V, _I, _F, _I]),
+    "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libweldacs.so is not built (%s). Run `python -m welding_robot_amd.build` "
+                              "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class WeldacsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, code), msg))
+        self.code = code

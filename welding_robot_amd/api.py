@@ -1,0 +1,255 @@
+"""Thin numpy-facing wrappers over the C ABI (include/weldacs.h) for tests and bench.py.
+All compute happens in libweldacs.so's HIP kernels; this file only marshals pointers."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import AcsParams, GtspParams, RNG_DEV, RNG_REF, WeldacsError  # noqa: F401
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.wa_ctx_create(device, C.byref(h))
+        if rc:
+            raise WeldacsError(rc, "wa_ctx_create(%d) failed: no usable HIP device" % device)
+        self.h = h
+
+    def check(self, rc):
+        if rc:
+            raise WeldacsError(rc, self.lib.wa_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.lib.wa_ctx_device_name(self.h, buf, 256)
+        return buf.value.decode()
+
+    @property
+    def stream(self):
+        return self.lib.wa_ctx_stream(self.h)
+
+    def sync(self):
+        self.check(self.lib.wa_ctx_sync(self.h))
+
+
+def stl_parse(data):
+    lib = L.load()
+    buf = np.frombuffer(data, np.uint8)
+    n = lib.wa_stl_parse(_ptr(buf), len(buf), None, 0)
+    if n < 0:
+        raise WeldacsError(-n, "wa_stl_parse")
+    tris = np.empty((n, 12), np.float32)
+    lib.wa_stl_parse(_ptr(buf), len(buf), _ptr(tris), n)
+    return tris
+
+
+def stl_read_file(path):
+    lib = L.load()
+    n = lib.wa_stl_read_file(path.encode(), None, 0)
+    if n < 0:
+        raise WeldacsError(-n, "wa_stl_read_file(%s)" % path)
+    tris = np.empty((n, 12), np.float32)
+    lib.wa_stl_read_file(path.encode(), _ptr(tris), n)
+    return tris
+
+
+def axis_coords(lo, hi, precision, wall, n):
+    out = np.empty(n, np.float32)
+    L.load().wa_axis_coords(C.c_float(lo), C.c_float(hi), C.c_float(precision), wall, n, _ptr(out))
+    return out
+
+
+class Grid:
+    def __init__(self, ctx, handle, bbox=None):
+        self.ctx, self.h, self.bbox = ctx, handle, bbox
+        dims = np.zeros(3, np.int32)
+        p, w, nf = C.c_float(), C.c_int32(), C.c_int64()
+        ctx.check(ctx.lib.wa_grid_info(self.h, _ptr(dims), C.byref(p), C.byref(w), C.byref(nf)))
+        self.nx, self.ny, self.nz = (int(v) for v in dims)
+        self.precision, self.wall, self.n_free = np.float32(p.value), w.value, nf.value
+
+    @classmethod
+    def from_mesh(cls, ctx, tris, precision, wall):
+        tris = np.ascontiguousarray(tris, np.float32)
+        h = C.c_void_p()
+        bbox = np.zeros(6, np.float32)
+        ctx.check(ctx.lib.wa_grid_from_mesh(ctx.h, _ptr(tris), len(tris), C.c_float(precision), wall, C.byref(h), _ptr(bbox)))
+        return cls(ctx, h, bbox)
+
+    @classmethod
+    def from_occupancy(cls, ctx, free, cx, cy, cz, precision, wall=0):
+        free = np.ascontiguousarray(free, np.uint8).reshape(-1)
+        cx, cy, cz = (np.ascontiguousarray(a, np.float32) for a in (cx, cy, cz))
+        assert free.size == len(cx) * len(cy) * len(cz)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.wa_grid_from_occupancy(ctx.h, _ptr(free), len(cx), len(cy), len(cz), _ptr(cx), _ptr(cy),
+                                                 _ptr(cz), C.c_float(precision), wall, C.byref(h)))
+        return cls(ctx, h)
+
+    @property
+    def n(self):
+        return self.nx * self.ny * self.nz
+
+    def occupancy(self):
+        out = np.empty(self.n, np.uint8)
+        self.ctx.check(self.ctx.lib.wa_grid_read_occupancy(self.h, _ptr(out)))
+        return out
+
+    def coords(self):
+        cx, cy, cz = np.empty(self.nx, np.float32), np.empty(self.ny, np.float32), np.empty(self.nz, np.float32)
+        self.ctx.check(self.ctx.lib.wa_grid_read_coords(self.h, _ptr(cx), _ptr(cy), _ptr(cz)))
+        return cx, cy, cz
+
+    def resolve(self, pts):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+        ids = np.empty(len(pts), np.int64)
+        self.ctx.check(self.ctx.lib.wa_grid_resolve_points(self.h, _ptr(pts), len(pts), _ptr(ids)))
+        return ids
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wa_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def default_params(**kw):
+    p = AcsParams()
+    L.load().wa_acs_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class AcsSolver:
+    def __init__(self, ctx, grid, n_slots=1, max_colony=256, path_capacity=0):
+        self.ctx, self.grid, self.n_slots, self.max_colony = ctx, grid, n_slots, max_colony
+        h = C.c_void_p()
+        ctx.check(ctx.lib.wa_acs_create(ctx.h, grid.h, n_slots, max_colony, path_capacity, C.byref(h)))
+        self.h = h
+        self.iters = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wa_acs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def init_pheromone(self, p0=1.0, slot=-1):
+        self.ctx.check(self.ctx.lib.wa_acs_init_pheromone(self.h, slot, C.c_float(p0)))
+
+    def reset_pheromone(self, p0=1.0, slot=-1):
+        self.ctx.check(self.ctx.lib.wa_acs_reset_pheromone(self.h, slot, C.c_float(p0)))
+
+    def srand(self, seed):
+        self.ctx.check(self.ctx.lib.wa_acs_srand(self.h, seed & 0xFFFFFFFF))
+
+    def rand_state(self, state=None):
+        st = np.zeros(36, np.int32) if state is None else np.ascontiguousarray(state, np.int32)
+        self.ctx.check(self.ctx.lib.wa_acs_rand_state(self.h, _ptr(st), 0 if state is None else 1))
+        return st
+
+    def _arrs(self, starts, ends, streams):
+        starts = np.ascontiguousarray(np.atleast_1d(starts), np.int64)
+        ends = np.ascontiguousarray(np.atleast_1d(ends), np.int64)
+        streams = None if streams is None else np.ascontiguousarray(np.atleast_1d(streams), np.uint32)
+        return starts, ends, streams
+
+    def begin(self, params, starts, ends, streams=None):
+        starts, ends, streams = self._arrs(starts, ends, streams)
+        self.n_active = len(starts)
+        self.iters = params.max_iteration
+        self.ctx.check(self.ctx.lib.wa_acs_begin(self.h, C.byref(params), len(starts), _ptr(starts), _ptr(ends), _ptr(streams)))
+
+    def run(self, n_generations):
+        self.ctx.check(self.ctx.lib.wa_acs_run(self.h, n_generations))
+
+    def sync(self):
+        self.ctx.check(self.ctx.lib.wa_acs_sync(self.h))
+
+    def solve(self, params, starts, ends, streams=None):
+        starts, ends, streams = self._arrs(starts, ends, streams)
+        self.n_active = len(starts)
+        self.iters = params.max_iteration
+        self.ctx.check(self.ctx.lib.wa_acs_solve(self.h, C.byref(params), len(starts), _ptr(starts), _ptr(ends), _ptr(streams)))
+
+    def result(self, slot=0):
+        cost, n = C.c_float(), C.c_int64()
+        self.ctx.check(self.ctx.lib.wa_acs_result(self.h, slot, C.byref(cost), C.byref(n), None, None, 0))
+        ids = np.empty(n.value, np.int32)
+        ch = np.empty(max(n.value - 1, 0), np.int8)
+        if n.value:
+            self.ctx.check(self.ctx.lib.wa_acs_result(self.h, slot, C.byref(cost), C.byref(n), _ptr(ids), _ptr(ch), n.value))
+        return np.float32(cost.value), ids, ch
+
+    def trace(self, slot=0):
+        g = C.c_int32()
+        self.ctx.check(self.ctx.lib.wa_acs_trace(self.h, slot, C.byref(g), None, None, None, None, None))
+        n = g.value
+        t = dict(bestL=np.zeros(n, np.float32), iterbestL=np.zeros(n, np.float32), colony=np.zeros(n, np.int32),
+                 finite=np.zeros(n, np.int32), steps=np.zeros(n, np.int64))
+        self.ctx.check(self.ctx.lib.wa_acs_trace(self.h, slot, C.byref(g), _ptr(t["bestL"]), _ptr(t["iterbestL"]),
+                                                 _ptr(t["colony"]), _ptr(t["finite"]), _ptr(t["steps"])))
+        return t
+
+    def export_trace(self, dst_device_ptr, gen0, count):
+        self.ctx.check(self.ctx.lib.wa_acs_export_trace(self.h, dst_device_ptr, gen0, count))
+
+    def pheromone(self, slot=0):
+        out = np.empty(self.grid.n * 6, np.float32)
+        self.ctx.check(self.ctx.lib.wa_acs_read_pheromone(self.h, slot, _ptr(out)))
+        return out
+
+    def last_params(self, slot=0):
+        c, l, q = C.c_int32(), C.c_float(), C.c_float()
+        self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))
+        return c.value, np.float32(l.value), np.float32(q.value)
+
+    def profile(self, enable=True, sample_every=1):
+        self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, 1 if enable else 0, sample_every))
+
+    def profile_read(self):
+        ms = np.zeros(L.K_COUNT, np.float64)
+        n = np.zeros(L.K_COUNT, np.int64)
+        self.ctx.check(self.ctx.lib.wa_acs_profile_read(self.h, _ptr(ms), _ptr(n)))
+        names = ["walk", "rank", "evaporate", "deposit"]
+        return {k: dict(ms=float(ms[i]), launches=int(n[i])) for i, k in enumerate(names)}
+
+    def evaporate(self, slot=0, rho=0.8, repeats=1):
+        self.ctx.check(self.ctx.lib.wa_acs_evaporate(self.h, slot, C.c_float(rho), repeats))
+
+
+def gtsp_solve(ctx, dist, cnt=None, mode=RNG_DEV, seed=1, stream=0, max_iterations=0, rand_state=None, want_pher=False):
+    dist = np.ascontiguousarray(dist, np.float64)
+    if dist.ndim == 2:
+        dist = dist[None]
+    inst, n = dist.shape[0], dist.shape[1]
+    cnt = n * (n - 1) // 2 if cnt is None else cnt
+    p = GtspParams(mode, seed, stream, max_iterations)
+    edges = np.zeros((inst, n, 2), np.int32)
+    cost = np.zeros(inst, np.float64)
+    iters = np.zeros(inst, np.int32)
+    pher = np.zeros((inst, n, n), np.float64) if want_pher else None
+    st = None if rand_state is None else np.ascontiguousarray(rand_state, np.int32)
+    ctx.check(ctx.lib.wa_gtsp_solve(ctx.h, _ptr(dist), n, cnt, inst, C.byref(p), _ptr(st), _ptr(edges), _ptr(cost),
+                                    _ptr(iters), _ptr(pher)))
+    return dict(edges=edges, L=cost, iters=iters, pher=pher, rand_state=st)

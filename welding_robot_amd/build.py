@@ -1,0 +1,56 @@
+"""Build libweldacs.so (the HIP/gfx950 product library) in-tree with hipcc.
+
+    python -m welding_robot_amd.build            # rebuild if sources changed
+
+Flags that matter for parity with the reference's fp32 semantics:
+  -ffp-contract=off                      no FMA contraction (x86-64 g++ without -mfma never contracts)
+  -fhip-fp32-correctly-rounded-divide-sqrt   IEEE '/' and sqrtf (hipcc default, spelled out)
+  -fno-fast-math, denormals kept (no -fgpu-flush-denormals-to-zero)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libweldacs.so")
+SOURCES = ["weldacs.hip"]
+DEPS = ["wa_device.h", "acs_kernels.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp"]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    files = [os.path.join(CSRC, f) for f in SOURCES + DEPS] + [HEADER, os.path.abspath(__file__)]
+    return any(os.path.getmtime(f) > t for f in files)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])
+    print(LIB_PATH)

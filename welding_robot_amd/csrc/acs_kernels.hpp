@@ -1,0 +1,614 @@
+// acs_kernels.hpp -- device side of ACS_Rank (ACSRank_3D.hpp), hand-written for gfx950 wave64.
+//
+//   k_init_pheromone  initFromGridMap :343-408 / reset :307-315         HBM write, 24 B/voxel
+//   k_heuristic       the (1 + beta*cos) factor of selectNext :151-154  once per problem
+//   k_begin           computeSolution prologue :229-233 + first :247-249
+//   k_walk<DEV>       one WAVEFRONT per ant: lanes 0-5 own the six neighbours   latency-bound
+//   k_walk<REF>       one wavefront per problem walks the ants in order on the libc stream
+//   k_rank            best update :263-264, rank :273-275, deposit coefficients, next :247-249
+//   k_evaporate       :268-272, float4 stream over 6N floats                     HBM-bound
+//   k_deposit_mark/_apply   update_pheromone :198-215, rank-ordered adds without float atomics
+//
+// fp32 semantics are the reference's: IEEE div/sqrt, denormals kept, no FMA
+// contraction (the TU is built with -ffp-contract=off), NaN propagation as written (Q3).
+#pragma once
+#include "wa_device.h"
+
+struct WaAcsDev {
+    WaDims d;
+    const float *cx, *cy, *cz;
+    const uint8_t *occ;            // free_[id]
+    float *pher, *heur;            // [slot][pher_stride]
+    unsigned long long *mask;      // [slot][pher_stride]
+    uint32_t *bestmark;            // [slot][n]
+    int32_t *bestpath;             // [slot][path_cap]
+    int32_t *paths;                // [slot][max_colony][path_cap]
+    float *antL;                   // [slot][max_colony]
+    int32_t *antLen;               // [slot][max_colony]
+    int32_t *perm;                 // [slot][max_colony]   rank o-1 -> ant
+    float *depA;                   // [slot][max_colony]   (lambda-o)*Q/L of rank o
+    float *sortk;                  // [slot][max_colony]   REF introsort scratch
+    int32_t *sortt;
+    uint32_t *vbits;               // [slot][max_colony][vbits_words] spill tabu bitmap (all zero at rest)
+    WaSlotCtl *ctl;                // [slot]
+    WaGlibcRand *rng;              // REF stream (one per solver, like the process-global rand())
+    float *trBest, *trIter;        // [slot][trace_cap]
+    int32_t *trColony, *trFinite;
+    long long *trSteps;
+    int64_t pher_stride;           // floats per slot (6N rounded up to 64)
+    int64_t path_cap;
+    int64_t vbits_words;
+    int32_t max_colony;
+    int32_t trace_cap;
+};
+
+__device__ __forceinline__ int32_t wa_delta(int k, int32_t nx, int32_t nxy)
+{
+    // edge order of ACSRank_3D.hpp:355-365: z-1, y-1, x-1, x+1, y+1, z+1
+    return k == 0 ? -nxy : k == 1 ? -nx : k == 2 ? -1 : k == 3 ? 1 : k == 4 ? nx : nxy;
+}
+
+// ------------------------------------------------------------------ pheromone init / reset
+// mode 0: initFromGridMap (out-of-bounds edges 0), mode 1: reset() (every edge pheromone_0).
+// The sign bit is set on edges whose neighbour is out of bounds or occupied.
+__global__ __launch_bounds__(256) void k_init_pheromone(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
+{
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= D.d.n) return;
+    int32_t slot = slot0 + blockIdx.y;
+    int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    float *p = D.pher + (int64_t)slot * D.pher_stride + id * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
+                Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
+        bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
+        bool adm = inb && D.occ[id + wa_delta(k, D.d.nx, D.d.nxy)] != 0;
+        float v = (inb || mode == 1) ? p0 : 0.f;
+        p[k] = adm ? v : -v;
+    }
+}
+
+// ------------------------------------------------------------------ heuristic field
+__global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta)
+{
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= D.d.n) return;
+    int32_t slot = blockIdx.y;
+    int32_t end = D.ctl[slot].end;
+    int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
+    float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
+    float na = sqrtf(ax * ax + ay * ay + az * az);
+    float *h = D.heur + (int64_t)slot * D.pher_stride + id * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
+                Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
+        float out = 0.f;
+        if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+            float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];  // :151
+            float dot = ax * bx + ay * by + az * bz;
+            float nb = sqrtf(bx * bx + by * by + bz * bz);
+            float c = dot / (na * nb);  // :152 (0/0 = NaN on a duplicated seam coordinate, Q3)
+            out = 1 + beta * c;         // :154
+        }
+        h[k] = out;
+    }
+}
+
+// :247-249 -- colony in double then truncated, lambda double -> float, Q float
+__device__ __forceinline__ void wa_next_params(WaSlotCtl &c, const WaRun &R)
+{
+    int32_t colony;
+    if (R.fixed_colony > 0) colony = R.fixed_colony;
+    else colony = (int32_t)(0.35 * (double)(c.bestL < R.predict ? c.bestL : R.predict) / (double)R.precision);
+    c.colony = colony;
+    c.lambda = (float)(0.2 * (double)colony);
+    c.Q = R.pheromone_0 / c.lambda * (c.bestL == INFINITY ? R.predict : c.bestL);
+}
+
+__global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long *starts,
+                        const long long *ends, const uint32_t *streams)
+{
+    int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_problems) return;
+    WaSlotCtl c = D.ctl[slot];
+    c.start = (int32_t)starts[slot];
+    c.end = (int32_t)ends[slot];
+    c.stream = streams ? streams[slot] : (uint32_t)slot;
+    c.gen = 0;
+    c.bestL = INFINITY;  // :232; the best PATH is kept (Q9) but unreachable while bestL is inf
+    c.best_len = 0;
+    c.n_dep = 0;
+    c.flags = 0;
+    wa_next_params(c, R);
+    D.ctl[slot] = c;
+}
+
+// ------------------------------------------------------------------ the walk
+// tabu set = open-addressing hash of voxel ids in LDS (the reference's std::set, :70,:145);
+// when a walk outgrows 3/4 of the table the wave spills to its private global bitmap.
+struct WaTabu {
+    int32_t *tab;
+    uint32_t mask, shift;
+    uint32_t *bits;
+    bool spilled;
+};
+__device__ __forceinline__ bool tabu_has(const WaTabu &t, int32_t key)
+{
+    if (t.spilled) {
+        uint32_t w = __hip_atomic_load(&t.bits[(uint32_t)key >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (w >> (key & 31)) & 1u;
+    }
+    uint32_t h = ((uint32_t)key * 2654435761u) >> t.shift;
+    for (;;) {
+        int32_t v = t.tab[h];
+        if (v == key) return true;
+        if (v == WA_HASH_EMPTY) return false;
+        h = (h + 1) & t.mask;
+    }
+}
+__device__ __forceinline__ void tabu_insert(const WaTabu &t, int32_t key)
+{
+    if (t.spilled) {
+        uint32_t old = atomicOr(&t.bits[(uint32_t)key >> 5], 1u << (key & 31));
+        asm volatile("" ::"v"(old));  // returning atomic: completed before the next lookup
+        return;
+    }
+    uint32_t h = ((uint32_t)key * 2654435761u) >> t.shift;
+    while (t.tab[h] != WA_HASH_EMPTY) h = (h + 1) & t.mask;
+    t.tab[h] = key;
+}
+
+template <int MODE>
+__device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
+                                            int32_t start, int32_t end, uint64_t key, int32_t *tab,
+                                            int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
+                                            int32_t *flags_out)
+{
+    const int lane = threadIdx.x;
+    const int32_t nx = D.d.nx, nxy = D.d.nxy;
+    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    WaTabu T;
+    T.tab = tab;
+    T.mask = (1u << hash_log2) - 1u;
+    T.shift = 32 - hash_log2;
+    T.bits = D.vbits + ((int64_t)slot * D.max_colony + ant) * D.vbits_words;
+    T.spilled = false;
+    const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
+
+    for (int i = lane; i <= (int)T.mask; i += 64) tab[i] = WA_HASH_EMPTY;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {  // addStartNode :81-86
+        path[0] = start;
+        tabu_insert(T, start);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    int32_t cur = start, len = 1;
+    uint32_t step = 0;
+    float L = 0.f;
+    const int k = lane;
+    const int32_t dk = wa_delta(k, nx, nxy);
+    for (;;) {
+        // ---- lanes 0..5: one neighbour each (:142-159)
+        float p = -0.f, h = 0.f;
+        bool adm = false;
+        if (k < 6) {
+            p = pher[(int64_t)cur * 6 + k];
+            h = heur[(int64_t)cur * 6 + k];
+            if ((__float_as_uint(p) >> 31) == 0)      // in bounds and free (:148)
+                adm = !tabu_has(T, cur + dk);         // not yet visited (:145-146)
+        }
+        float info = wa_powi(fabsf(p), R.alpha) * h;  // :154
+        uint32_t m = (uint32_t)__ballot(adm) & 0x3fu;
+        if (m == 0) { L = INFINITY; break; }          // :162-166
+        float v[6];
+        float total = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
+            if ((m >> i) & 1u) total += v[i];         // :155, forward order
+        }
+        int32_t r;
+        if (MODE == 1) r = (int32_t)wa_ctr_draw(key, (uint32_t)ant, step);
+        else r = wa_glibc_next(rng_r, rng_f, rng_b);   // every lane advances its own copy in lockstep
+        float rnd = (float)r / 2147483648.0f;          // (float)RAND_MAX == 2^31 (:169)
+        rnd *= total;                                  // :170
+        float prob = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {                 // reverse cumulative order (:172-189)
+            if (pick < 0 && ((m >> i) & 1u)) {
+                prob += v[i];
+                if (prob >= rnd) pick = i;
+            }
+        }
+        if (pick < 0) { L = INFINITY; break; }         // :191-192
+        int32_t next = cur + wa_delta(pick, nx, nxy);
+        if (len >= D.path_cap) {
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+            L = INFINITY;
+            break;
+        }
+        if (lane == 0) {                               // addNextNode :73-79
+            path[len] = next | (pick << WA_K_SHIFT);
+            tabu_insert(T, next);
+        }
+        __builtin_amdgcn_wave_barrier();
+        len++;
+        L += R.precision;                              // distance == precision (:378)
+        step++;
+        if (next == end) break;                        // :182-186
+        cur = next;
+        if (!T.spilled && len > spill_at) {            // hash nearly full: move the set to the bitmap
+            __threadfence();
+            for (int i = lane; i < len; i += 64) {
+                int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
+                uint32_t old = atomicOr(&T.bits[(uint32_t)id >> 5], 1u << (id & 31));
+                asm volatile("" ::"v"(old));
+            }
+            __threadfence();
+            T.spilled = true;
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_BITMAP_USED);
+        }
+    }
+    if (T.spilled) {  // leave the bitmap all-zero for the next walk
+        __threadfence();
+        for (int i = lane; i < len; i += 64) {
+            int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
+            __hip_atomic_store(&T.bits[(uint32_t)id >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+    }
+    if (lane == 0) {
+        D.antL[(int64_t)slot * D.max_colony + ant] = L;
+        D.antLen[(int64_t)slot * D.max_colony + ant] = len;
+    }
+}
+
+// DEV: grid = (max_colony, n_problems), block = one wavefront
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2)
+{
+    extern __shared__ int32_t lds[];
+    const int32_t slot = blockIdx.y, ant = blockIdx.x;
+    const WaSlotCtl *c = &D.ctl[slot];
+    if (ant >= c->colony) return;
+    if (c->colony > D.max_colony) return;  // flagged by k_rank
+    uint64_t key = wa_ctr_key(R.seed, c->stream, (uint32_t)c->gen);
+    int32_t f = 0, b = 0;
+    wa_walk_one<1>(D, R, slot, ant, c->start, c->end, key, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+}
+
+// REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
+// from the shared glibc stream in exactly the reference's order (:252-261)
+__global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2)
+{
+    extern __shared__ int32_t lds[];
+    const int32_t slot = blockIdx.y;
+    const WaSlotCtl *c = &D.ctl[slot];
+    int32_t colony = c->colony;
+    if (colony > D.max_colony) return;
+    // every lane keeps a private copy of the 31-word state in registers/scratch: all lanes draw
+    // in lockstep, so the copies stay identical and no cross-lane traffic is needed
+    int32_t r[31];
+    for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
+    int32_t f = D.rng->f, b = D.rng->b;
+    const int32_t start = c->start, end = c->end;
+    for (int32_t ant = 0; ant < colony; ant++)
+        wa_walk_one<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
+        D.rng->f = f;
+        D.rng->b = b;
+    }
+}
+
+// ------------------------------------------------------------------ libstdc++ std::sort order
+// (bits/stl_algo.h introsort + bits/stl_heap.h, GCC 11) restated for one thread on (key, tag)
+// records; reproduces the permutation the reference gets from std::sort at :273.
+struct WaRec { float k; int32_t t; };
+__device__ inline void ss_push_heap(WaRec *first, long hole, long top, WaRec value)
+{
+    long parent = (hole - 1) / 2;
+    while (hole > top && first[parent].k < value.k) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+__device__ inline void ss_adjust_heap(WaRec *first, long hole, long len, WaRec value)
+{
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (first[child].k < first[child - 1].k) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    ss_push_heap(first, hole, top, value);
+}
+__device__ inline void ss_heap_sort(WaRec *first, WaRec *last)
+{
+    long len = last - first;
+    if (len >= 2) {
+        long parent = (len - 2) / 2;
+        for (;;) {
+            WaRec v = first[parent];
+            ss_adjust_heap(first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {
+        --last;
+        WaRec v = *last;
+        *last = *first;
+        ss_adjust_heap(first, 0, last - first, v);
+    }
+}
+__device__ inline void ss_swap(WaRec *a, WaRec *b) { WaRec t = *a; *a = *b; *b = t; }
+__device__ inline void ss_unguarded_linear_insert(WaRec *last)
+{
+    WaRec v = *last;
+    WaRec *next = last - 1;
+    while (v.k < next->k) { *last = *next; last = next; --next; }
+    *last = v;
+}
+__device__ inline void ss_insertion_sort(WaRec *first, WaRec *last)
+{
+    if (first == last) return;
+    for (WaRec *i = first + 1; i != last; ++i) {
+        if (i->k < first->k) {
+            WaRec v = *i;
+            for (WaRec *j = i; j != first; --j) *j = *(j - 1);
+            *first = v;
+        } else ss_unguarded_linear_insert(i);
+    }
+}
+__device__ inline void wa_std_sort(WaRec *v, int32_t n)
+{
+    if (n <= 0) return;
+    long lg = 0;
+    for (unsigned long m = (unsigned long)n; m > 1; m >>= 1) lg++;
+    // __introsort_loop with its tail recursion turned into an explicit stack
+    struct Frame { WaRec *first, *last; long depth; };
+    Frame stack[72];
+    int sp = 0;
+    stack[sp++] = {v, v + n, 2 * lg};
+    while (sp > 0) {
+        Frame fr = stack[--sp];
+        WaRec *first = fr.first, *last = fr.last;
+        long depth = fr.depth;
+        while (last - first > 16) {
+            if (depth == 0) { ss_heap_sort(first, last); break; }
+            --depth;
+            WaRec *mid = first + (last - first) / 2;
+            WaRec *a = first + 1, *b = mid, *c = last - 1;  // __move_median_to_first
+            if (a->k < b->k) {
+                if (b->k < c->k) ss_swap(first, b);
+                else if (a->k < c->k) ss_swap(first, c);
+                else ss_swap(first, a);
+            } else if (a->k < c->k) ss_swap(first, a);
+            else if (b->k < c->k) ss_swap(first, c);
+            else ss_swap(first, b);
+            WaRec *lo = first + 1, *hi = last;  // __unguarded_partition, pivot = *first
+            for (;;) {
+                while (lo->k < first->k) ++lo;
+                --hi;
+                while (first->k < hi->k) --hi;
+                if (!(lo < hi)) break;
+                ss_swap(lo, hi);
+                ++lo;
+            }
+            // the reference recurses on [cut,last) FIRST, then loops on [first,cut).  The two
+            // ranges are disjoint, so the order of processing does not change the result.
+            stack[sp++] = {lo, last, depth};
+            last = lo;
+        }
+    }
+    if (n > 16) {
+        ss_insertion_sort(v, v + 16);
+        for (WaRec *i = v + 16; i != v + n; ++i) ss_unguarded_linear_insert(i);
+    } else ss_insertion_sort(v, v + n);
+}
+
+// ------------------------------------------------------------------ rank
+// one workgroup per problem: iteration best -> global best (strict <, first ant wins :263-264),
+// ranking (:273-275), per-rank deposit coefficient, trace, next generation's parameters.
+__global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
+{
+    const int32_t slot = blockIdx.x, tid = threadIdx.x;
+    WaSlotCtl *ctl = &D.ctl[slot];
+    const int32_t colony = ctl->colony;
+    const int32_t gen = ctl->gen;
+    const float *antL = D.antL + (int64_t)slot * D.max_colony;
+    const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
+    int32_t *perm = D.perm + (int64_t)slot * D.max_colony;
+    float *depA = D.depA + (int64_t)slot * D.max_colony;
+    __shared__ unsigned long long s_min;
+    __shared__ int32_t s_fin, s_ndep;
+    __shared__ unsigned long long s_steps;
+    if (tid == 0) { s_min = ~0ULL; s_fin = 0; s_ndep = 0; s_steps = 0; }
+    __syncthreads();
+    if (colony > D.max_colony) {
+        if (tid == 0) { atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW); ctl->gen = gen + 1; }
+        return;
+    }
+    // L >= 0 or +inf, so the uint32 order of the bit pattern is the float order
+    unsigned long long mykey = ~0ULL;
+    int32_t myfin = 0;
+    unsigned long long mysteps = 0;
+    for (int32_t a = tid; a < colony; a += blockDim.x) {
+        float La = antL[a];
+        unsigned long long key = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
+        mykey = key < mykey ? key : mykey;
+        myfin += (La != INFINITY) ? 1 : 0;
+        mysteps += (unsigned long long)(antLen[a] - 1);
+    }
+    atomicMin(&s_min, mykey);
+    atomicAdd(&s_fin, myfin);
+    atomicAdd(&s_steps, mysteps);
+    __syncthreads();
+    float iterL = INFINITY;
+    int32_t iterAnt = -1;
+    if (colony > 0) { iterL = __uint_as_float((uint32_t)(s_min >> 32)); iterAnt = (int32_t)(s_min & 0xffffffffu); }
+    float bestL = ctl->bestL;
+    uint32_t ver = ctl->best_ver;
+    __syncthreads();
+    if (iterAnt >= 0 && iterL < bestL) {  // best = agentK (:264): copy the path, re-stamp membership
+        const int32_t blen = antLen[iterAnt];
+        const int32_t *src = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
+        int32_t *dst = D.bestpath + (int64_t)slot * D.path_cap;
+        uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+        ver = ver + 1;
+        for (int32_t i = tid; i < blen; i += blockDim.x) {
+            int32_t w = src[i];
+            dst[i] = w;
+            mark[w & WA_ID_MASK] = ver;
+        }
+        bestL = iterL;
+        if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; }
+    }
+    // ---- ranking
+    if (R.rng_mode == 1) {  // DEV: ascending (L, ant) by counting
+        for (int32_t a = tid; a < colony; a += blockDim.x) {
+            unsigned long long ka = ((unsigned long long)__float_as_uint(antL[a]) << 32) | (uint32_t)a;
+            int32_t r = 0;
+            for (int32_t b = 0; b < colony; b++) {
+                unsigned long long kb = ((unsigned long long)__float_as_uint(antL[b]) << 32) | (uint32_t)b;
+                r += kb < ka ? 1 : 0;
+            }
+            perm[r] = a;
+        }
+    } else if (tid == 0) {  // REF: libstdc++'s permutation
+        WaRec *rec = (WaRec *)(D.sortk + (int64_t)slot * D.max_colony * 2);
+        for (int32_t a = 0; a < colony; a++) { rec[a].k = antL[a]; rec[a].t = a; }
+        wa_std_sort(rec, colony);
+        for (int32_t a = 0; a < colony; a++) perm[a] = rec[a].t;
+    }
+    __syncthreads();
+    // ---- deposit coefficients of update_pheromone (:200,:211)
+    const float lambda = ctl->lambda, Q = ctl->Q;
+    int32_t myndep = 0;
+    for (int32_t o = 1 + tid; o <= colony; o += blockDim.x) {
+        float La = antL[perm[o - 1]];
+        bool ok = !(La == INFINITY || (float)o > lambda - 1);
+        depA[o - 1] = ok ? (lambda - (float)o) * Q / La : 0.f;
+        if (ok) myndep = o;
+    }
+    atomicMax(&s_ndep, myndep);
+    __syncthreads();
+    if (tid == 0) {
+        if (gen < D.trace_cap) {
+            int64_t t = (int64_t)slot * D.trace_cap + gen;
+            D.trBest[t] = bestL;
+            D.trIter[t] = iterL;
+            D.trColony[t] = colony;
+            D.trFinite[t] = s_fin;
+            D.trSteps[t] = (long long)s_steps;
+        }
+        WaSlotCtl c = *ctl;
+        c.bestL = bestL;
+        c.dep_lambda = lambda;
+        c.dep_Q = Q;
+        c.dep_bestL = bestL;
+        c.n_dep = s_ndep;
+        c.gen = gen + 1;
+        wa_next_params(c, R);
+        *ctl = c;
+    }
+}
+
+// ------------------------------------------------------------------ evaporation (the HBM sweep)
+// :268-272 -- every edge of every voxel, occupied voxels and out-of-bounds edges included.
+// 48 B of traffic per voxel (24 read + 24 written).  float4 per lane, 4 independent float4
+// in flight per thread, grid-stride.
+__global__ __launch_bounds__(256) void k_evaporate(float *__restrict__ pher, int64_t stride, int64_t n_floats, float rho)
+{
+    float *base = pher + (int64_t)blockIdx.y * stride;
+    float4 *p4 = reinterpret_cast<float4 *>(base);
+    const int64_t n4 = n_floats >> 2;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * gsz < n4; i += 4 * gsz) {
+        float4 a = p4[i], b = p4[i + gsz], c = p4[i + 2 * gsz], d = p4[i + 3 * gsz];
+        a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
+        b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
+        c.x *= rho; c.y *= rho; c.z *= rho; c.w *= rho;
+        d.x *= rho; d.y *= rho; d.z *= rho; d.w *= rho;
+        p4[i] = a; p4[i + gsz] = b; p4[i + 2 * gsz] = c; p4[i + 3 * gsz] = d;
+    }
+    for (; i < n4; i += gsz) {
+        float4 a = p4[i];
+        a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
+        p4[i] = a;
+    }
+    // tail (n_floats = 6N is even; at most 2 floats)
+    int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_floats) base[t] *= rho;
+}
+
+// ------------------------------------------------------------------ ranked deposit
+// update_pheromone (:198-215) adds, per ranked ant in rank order, a float to every directed edge
+// of its path.  Float adds do not commute, so instead of atomics: pass 1 ORs bit (o-1-base) into
+// a per-edge rank mask; pass 2 lets the LOWEST rank present on an edge own it and apply all
+// present ranks in ascending order (= the reference's order), then clear the mask.
+// grid = (blocks, 64 ranks, n_problems)
+__global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
+{
+    const int32_t slot = blockIdx.z, bit = blockIdx.y, o = base + bit + 1;
+    const WaSlotCtl *c = &D.ctl[slot];
+    if (o > c->n_dep) return;
+    const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
+    const int32_t len = D.antLen[(int64_t)slot * D.max_colony + a];
+    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
+    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    for (int32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+        int32_t w = path[i];
+        int32_t v = path[i - 1] & WA_ID_MASK;
+        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        atomicOr(&mask[e], 1ULL << bit);
+    }
+}
+__global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
+{
+    const int32_t slot = blockIdx.z, bit = blockIdx.y, o = base + bit + 1;
+    const WaSlotCtl *c = &D.ctl[slot];
+    if (o > c->n_dep) return;
+    const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
+    const int32_t len = D.antLen[(int64_t)slot * D.max_colony + a];
+    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
+    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const float *depA = D.depA + (int64_t)slot * D.max_colony;
+    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    const uint32_t ver = c->best_ver;
+    const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
+    for (int32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+        int32_t w = path[i];
+        int32_t v = path[i - 1] & WA_ID_MASK;
+        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        unsigned long long m = mask[e];
+        if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
+        bool onbest = mark[v] == ver && mark[w & WA_ID_MASK] == ver;  // :209
+        float p = pher[e];
+        while (m) {
+            int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            p += depA[base + b] + (float)onbest * lambda * Q / bestL;  // :210-211
+        }
+        pher[e] = p;
+        mask[e] = 0;
+    }
+}

@@ -1,0 +1,157 @@
+// gtsp_kernels.hpp -- device side of ACS_GTSP (ACS_GTSP.hpp): the weld-seam ordering loop.
+//
+// One workgroup per TSP instance runs the whole computeSolution loop (:255-284) without host
+// round trips; one thread per ant (colony = city_num, :192).  fp64 throughout, operations in the
+// reference's order: info = pheromone^1 * (h^2 * h^4) (:117-118 through power()), roulette over
+// the unvisited set in ascending city order with >= (:127-142), tour length without the closing
+// edge (:36-44), evaporation by (1 - 0.1) then iteration-best deposit on all N edges with the
+// symmetric copy (:175-184), stop after city_num+1 non-improving iterations (:263,:269-275).
+#pragma once
+#include "wa_device.h"
+
+struct WaGtspDev {
+    const double *dist;   // [inst][n*n]
+    double *pher, *h6, *info;  // [inst][n*n]
+    double *antL;         // [inst][n]
+    int32_t *tours;       // [inst][n ants][n steps][2]
+    int32_t *best;        // [inst][n][2]
+    uint8_t *inJ;         // [inst][n ants][n]
+    int32_t *rbuf;        // REF: n*(n-1) draws of the current iteration
+    WaGlibcRand *rng;     // REF
+    double *out_cost;     // [inst]
+    int32_t *out_iters;   // [inst]
+    int32_t n, cnt, max_iterations, rng_mode;
+    uint64_t seed;
+    uint32_t stream0;
+};
+
+__global__ __launch_bounds__(256) void k_gtsp(WaGtspDev G)
+{
+    const int32_t inst = blockIdx.x, tid = threadIdx.x, n = G.n;
+    const int64_t nn = (int64_t)n * n;
+    const double *dist = G.dist + inst * nn;
+    double *pher = G.pher + inst * nn, *h6 = G.h6 + inst * nn, *info = G.info + inst * nn;
+    double *antL = G.antL + (int64_t)inst * n;
+    int32_t *tours = G.tours + inst * nn * 2;
+    int32_t *best = G.best + (int64_t)inst * n * 2;
+    uint8_t *inJ = G.inJ + inst * nn;
+    const double INF = (double)0x3f3f3f3f;  // ACS_GTSP.hpp:19
+    const double alpha = 0.1;               // :189
+    __shared__ double s_pher0, s_bestL, s_last, s_nowL;
+    __shared__ int32_t s_bad, s_nowk, s_stop, s_it;
+
+    // readFromGraphFile :239-249 + init_param :201-213
+    if (tid == 0) {
+        double tmp = 0;
+        for (int32_t i = 0; i < n; i++)
+            for (int32_t j = i + 1; j < n; j++) tmp += dist[(int64_t)i * n + j];
+        s_pher0 = (double)G.cnt / (tmp * n);
+        s_bestL = INF;
+        s_last = INF;
+        s_bad = 0;
+        s_stop = 0;
+        s_it = 0;
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < nn; e += blockDim.x) {
+        int32_t i = (int32_t)(e / n), j = (int32_t)(e % n);
+        pher[e] = s_pher0;
+        double h = 1 / ((i == j ? 0.0 : dist[e]) + 1e-8);  // :211
+        h6[e] = wa_powi(h, 6);                               // power(herustic, beta = 6) :118
+    }
+    __syncthreads();
+    const int32_t max_it = G.max_iterations > 0 ? G.max_iterations : n * n;  // :216
+    int32_t rf = 0, rb = 0;
+    int32_t rr[31];
+    if (G.rng_mode == 0 && tid == 0) {
+        for (int i = 0; i < 31; i++) rr[i] = G.rng->r[i];
+        rf = G.rng->f;
+        rb = G.rng->b;
+    }
+    for (int32_t it = 0; it < max_it; it++) {
+        if (tid == 0) s_stop = s_bad > n ? 1 : 0;  // :263
+        __syncthreads();
+        if (s_stop) break;
+        // reset :103-120
+        for (int64_t e = tid; e < nn; e += blockDim.x) {
+            info[e] = wa_powi(pher[e], 1) * h6[e];
+            inJ[e] = (e / n) == (e % n) ? 0 : 1;
+        }
+        if (G.rng_mode == 0 && tid == 0)  // the libc draws of this iteration in (step, ant) order
+            for (int32_t q = 0; q < n * (n - 1); q++) G.rbuf[q] = wa_glibc_next(rr, rf, rb);
+        __syncthreads();
+        // construct_solution :146-159 -- ants are independent once the draws are fixed
+        const uint64_t key = wa_ctr_key(G.seed, G.stream0 + (uint32_t)inst, (uint32_t)it);
+        for (int32_t k = tid; k < n; k += blockDim.x) {
+            uint8_t *J = inJ + (int64_t)k * n;
+            int32_t r = k, left = n - 1;
+            for (int32_t step = 0; step < n; step++) {
+                int32_t next = k;  // r1[k]
+                if (left > 0) {    // select_next :122-144
+                    int32_t rv = G.rng_mode == 0 ? G.rbuf[step * n + k]
+                                                 : (int32_t)wa_ctr_draw(key, (uint32_t)k, (uint32_t)step);
+                    double rnd = (double)rv / (double)2147483647;
+                    const double *row = info + (int64_t)r * n;
+                    double sum = 0, sp = 0;
+                    for (int32_t c = 0; c < n; c++)
+                        if (J[c]) sum += row[c];
+                    rnd *= sum;
+                    for (int32_t c = 0; c < n; c++)
+                        if (J[c]) {
+                            sp += row[c];
+                            if (sp >= rnd) { next = c; break; }
+                        }
+                }
+                if (J[next]) { J[next] = 0; left--; }
+                tours[((int64_t)k * n + step) * 2] = r;
+                tours[((int64_t)k * n + step) * 2 + 1] = next;
+                r = next;
+            }
+            double L = 0;  // ACS_Tour::calc :36-44
+            for (int32_t e = 0; e < n - 1; e++) {
+                int32_t a = tours[((int64_t)k * n + e) * 2], b = tours[((int64_t)k * n + e) * 2 + 1];
+                L += a == b ? 0.0 : dist[(int64_t)a * n + b];
+            }
+            antL[k] = L;
+        }
+        __syncthreads();
+        // update_pheromone :161-185
+        if (tid == 0) {
+            double nowL = INF;
+            int32_t nowk = -1;
+            for (int32_t k = 0; k < n; k++)
+                if (antL[k] < nowL) { nowL = antL[k]; nowk = k; }
+            s_nowL = nowL;
+            s_nowk = nowk;
+        }
+        __syncthreads();
+        const int32_t nowk = s_nowk;
+        if (nowk >= 0 && s_nowL < s_bestL)
+            for (int32_t e = tid; e < 2 * n; e += blockDim.x) best[e] = tours[(int64_t)nowk * n * 2 + e];
+        for (int64_t e = tid; e < nn; e += blockDim.x) pher[e] *= (1 - alpha);
+        __syncthreads();
+        if (tid == 0) {
+            if (nowk >= 0) {
+                if (s_nowL < s_bestL) s_bestL = s_nowL;
+                for (int32_t e = 0; e < n; e++) {
+                    int32_t a = tours[((int64_t)nowk * n + e) * 2], b = tours[((int64_t)nowk * n + e) * 2 + 1];
+                    pher[(int64_t)a * n + b] += 1. / (double)s_nowL;
+                    pher[(int64_t)b * n + a] = pher[(int64_t)a * n + b];
+                }
+            }
+            if (s_last > s_bestL) { s_last = s_bestL; s_bad = 0; }
+            else s_bad++;
+            s_it = it + 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        G.out_cost[inst] = s_bestL;
+        G.out_iters[inst] = s_it;
+        if (G.rng_mode == 0) {
+            for (int i = 0; i < 31; i++) G.rng->r[i] = rr[i];
+            G.rng->f = rf;
+            G.rng->b = rb;
+        }
+    }
+}

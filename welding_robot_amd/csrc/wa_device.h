@@ -1,0 +1,115 @@
+// wa_device.h -- shared host/device definitions of libweldacs (gfx950).
+//
+// Data layout in HBM (per solver, per problem slot) -- see DESIGN.md:
+//   pher  float[6N]  pheromone of directed edge (voxel, k); the SIGN BIT carries the static
+//                    admissibility of the edge (set = neighbour out of bounds or occupied), so
+//                    one 24-byte load per step answers both ACSRank_3D.hpp:148 and :154.
+//                    |value| is bit-identical to the reference's adjacency_infos[k].pheromone.
+//   heur  float[6N]  (1 + beta*cos) of ACSRank_3D.hpp:151-154 for the slot's end node
+//   mask  u64[6N]    deposit rank masks (zero between generations)
+//   paths int32[max_colony][path_cap]  node id | (edge k taken to arrive << 29)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WA_K_SHIFT 29
+#define WA_ID_MASK 0x1FFFFFFFu
+#define WA_HASH_EMPTY (-1)
+#define WA_MAX_TRACKED_ERR 1
+
+enum { WA_FLAG_PATH_OVERFLOW = 1, WA_FLAG_COLONY_OVERFLOW = 2, WA_FLAG_BITMAP_USED = 4 };
+
+struct WaDims {
+    int32_t nx, ny, nz;
+    int32_t nxy;      // nx*ny
+    int64_t n;        // nx*ny*nz
+};
+
+// run-constant parameters (ACSRank_3D.hpp:319-326 + the call-site predict)
+struct WaRun {
+    int32_t alpha;
+    float beta, rho, pheromone_0, predict, precision;
+    int32_t fixed_colony;
+    int32_t rng_mode;
+    uint64_t seed;
+};
+
+// per-slot control block, lives in device memory, updated by the kernels only
+struct WaSlotCtl {
+    int32_t start, end;
+    uint32_t stream;
+    int32_t gen;            // generation about to be walked
+    int32_t colony;         // ants of that generation           (:247)
+    float lambda, Q;        // of that generation                (:248-249)
+    float bestL;            // best.L                            (:232,:263)
+    int32_t best_len;
+    uint32_t best_ver;      // bestmark[v] == best_ver <=> v on best path
+    // frozen for the deposit of the generation just walked
+    float dep_lambda, dep_Q, dep_bestL;
+    int32_t n_dep;          // ranks 1..n_dep deposit             (:200)
+    int32_t flags;
+    int32_t pad;
+};
+
+// glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index
+struct WaGlibcRand {
+    int32_t r[34];
+    int32_t f, b;
+};
+
+__host__ __device__ inline uint64_t wa_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// DEV-mode draw: pure function of (seed, stream, generation, ant, step); identical to
+// wo_ctr_rand31 in oracle/weld_oracle.c
+__host__ __device__ inline uint64_t wa_ctr_key(uint64_t seed, uint32_t stream, uint32_t gen)
+{
+    return wa_mix64(seed + 0x9E3779B97F4A7C15ULL * (((uint64_t)stream << 32) | gen));
+}
+__host__ __device__ inline uint32_t wa_ctr_draw(uint64_t key, uint32_t ant, uint32_t step)
+{
+    uint64_t v = wa_mix64(key + 0x9E3779B97F4A7C15ULL * ((((uint64_t)ant << 32) | step) + 1));
+    return (uint32_t)(v >> 33);
+}
+
+// glibc random_r TYPE_3 (stdlib/random_r.c): the stream behind the reference's rand()
+__host__ __device__ inline int32_t wa_glibc_next(int32_t *r, int32_t &f, int32_t &b)
+{
+    uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+    r[f] = (int32_t)v;
+    if (++f >= 31) { f = 0; ++b; }
+    else if (++b >= 31) b = 0;
+    return (int32_t)((v >> 1) & 0x7fffffffu);
+}
+__host__ inline void wa_glibc_seed(WaGlibcRand *s, uint32_t seed)
+{
+    if (seed == 0) seed = 1;
+    int32_t word = (int32_t)seed;
+    s->r[0] = word;
+    for (int i = 1; i < 31; i++) {
+        long hi = word / 127773, lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int32_t)w;
+        s->r[i] = word;
+    }
+    s->f = 3;
+    s->b = 0;
+    for (int i = 0; i < 310; i++) (void)wa_glibc_next(s->r, s->f, s->b);
+}
+
+// power() of ACSRank_3D.hpp:48-60
+template <class T>
+__host__ __device__ inline T wa_powi(T x, int y)
+{
+    T ans = 1;
+    while (y) {
+        if (y & 1) ans *= x;
+        x *= x;
+        y >>= 1;
+    }
+    return ans;
+}

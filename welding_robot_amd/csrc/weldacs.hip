@@ -1,0 +1,783 @@
+// weldacs.hip -- C ABI of libweldacs.so (include/weldacs.h) over the gfx950 kernels.
+// Single translation unit: hipcc --offload-arch=gfx950 -ffp-contract=off (see build.py).
+// There is no CPU compute path in this library: without a HIP device wa_ctx_create fails.
+#include "../../include/weldacs.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "acs_kernels.hpp"
+#include "grid_kernels.hpp"
+#include "gtsp_kernels.hpp"
+
+// ------------------------------------------------------------------ handles
+struct wa_ctx {
+    int device;
+    hipStream_t stream;
+    std::string err;
+    hipDeviceProp_t prop;
+};
+struct wa_grid {
+    wa_ctx *ctx;
+    WaDims d;
+    float precision;
+    int32_t wall;
+    int64_t n_free;
+    float *cx, *cy, *cz;   // device
+    uint8_t *occ;          // device
+};
+struct EvPair { hipEvent_t a, b; int cls; };
+struct wa_acs {
+    wa_ctx *ctx;
+    const wa_grid *grid;
+    int32_t n_slots, max_colony, n_active;
+    int64_t path_cap;
+    WaAcsDev D;
+    WaRun R;
+    bool begun;
+    int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
+    long long *d_starts, *d_ends;
+    uint32_t *d_streams;
+    // profiling
+    bool prof;
+    int32_t prof_every;
+    std::vector<EvPair> ev;
+    double prof_ms[WA_K_COUNT];
+    int64_t prof_n[WA_K_COUNT];
+};
+
+static int fail(wa_ctx *c, int code, const char *fmt, const char *a = "")
+{
+    if (c) {
+        char buf[512];
+        snprintf(buf, sizeof buf, fmt, a);
+        c->err = buf;
+    }
+    return code;
+}
+#define HIPC(ctx, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail((ctx), WA_ERR_DEVICE, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T **p, size_t count)
+{
+    return hipMalloc((void **)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+}
+
+extern "C" {
+
+const char *wa_version(void) { return "weldacs 0.1 (gfx950)"; }
+
+int wa_ctx_create(int device_ordinal, wa_ctx **out)
+{
+    if (!out) return WA_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return WA_ERR_DEVICE;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return WA_ERR_DEVICE;
+    wa_ctx *c = new wa_ctx();
+    c->device = device_ordinal;
+    if (hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return WA_ERR_DEVICE;
+    }
+    *out = c;
+    return WA_OK;
+}
+void wa_ctx_destroy(wa_ctx *c)
+{
+    if (!c) return;
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+const char *wa_last_error(const wa_ctx *c) { return c ? c->err.c_str() : "no context"; }
+int wa_ctx_device_name(const wa_ctx *c, char *buf, size_t cap)
+{
+    if (!c || !buf || !cap) return WA_ERR_ARG;
+    snprintf(buf, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    return WA_OK;
+}
+int wa_ctx_sync(wa_ctx *c)
+{
+    if (!c) return WA_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return WA_OK;
+}
+void *wa_ctx_stream(wa_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ------------------------------------------------------------------ STL (read_STL.hpp)
+int64_t wa_stl_parse(const void *buf, size_t len, float *tris, int64_t cap_tris)
+{
+    const uint8_t *b = (const uint8_t *)buf;
+    if (!b) return -WA_ERR_ARG;
+    if (len < 84) return -WA_ERR_FILE;            // shorter than header + count
+    if (b[79] != 0) return -WA_ERR_FORMAT;        // ASCII sniff (:65); ASCII carries no usable normals (Q11)
+    int32_t n;
+    memcpy(&n, b + 80, 4);                         // cpyint :158
+    if (n < 0 || (size_t)n * 50 + 84 > len) return -WA_ERR_FILE;
+    if (!tris) return n;
+    if (cap_tris < n) return -WA_ERR_CAPACITY;
+    const uint8_t *p = b + 84;
+    for (int64_t i = 0; i < n; i++, p += 50) memcpy(tris + i * 12, p, 48);  // :142-151
+    return n;
+}
+int64_t wa_stl_read_file(const char *path, float *tris, int64_t cap_tris)
+{
+    if (!path) return -WA_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -WA_ERR_FILE;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    rewind(f);
+    std::vector<uint8_t> buf(sz > 0 ? (size_t)sz : 0);
+    size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if ((long)got != sz) return -WA_ERR_FILE;
+    return wa_stl_parse(buf.data(), buf.size(), tris, cap_tris);
+}
+
+// ------------------------------------------------------------------ grid
+int wa_axis_coords(float lo, float hi, float precision, int32_t wall, int32_t n, float *out)
+{
+    if (!out || n < 0) return WA_ERR_ARG;
+    for (int32_t i = 0; i < n; i++)  // model_grid_map.hpp:204-211
+        out[i] = i < wall ? lo - (float)(wall - i) * precision
+                          : (i >= (n - wall) ? hi + (float)(i - n + wall) * precision : lo + (float)(i - wall) * precision);
+    return WA_OK;
+}
+
+static int grid_alloc(wa_ctx *ctx, int32_t nx, int32_t ny, int32_t nz, const float *cx, const float *cy,
+                      const float *cz, float precision, int32_t wall, wa_grid **out)
+{
+    if (nx < 1 || ny < 1 || nz < 1) return fail(ctx, WA_ERR_ARG, "grid dimensions must be >= 1");
+    int64_t n = (int64_t)nx * ny * nz;
+    if (n > (int64_t)WA_ID_MASK) return fail(ctx, WA_ERR_ARG, "grid larger than 2^29 voxels");
+    wa_grid *g = new wa_grid();
+    g->ctx = ctx;
+    g->d.nx = nx; g->d.ny = ny; g->d.nz = nz; g->d.nxy = nx * ny; g->d.n = n;
+    g->precision = precision;
+    g->wall = wall;
+    g->n_free = -1;
+    g->cx = g->cy = g->cz = nullptr;
+    g->occ = nullptr;
+    if (dalloc(&g->cx, nx) || dalloc(&g->cy, ny) || dalloc(&g->cz, nz) || dalloc(&g->occ, n)) {
+        wa_grid_destroy(g);
+        return fail(ctx, WA_ERR_ALLOC, "grid device allocation failed");
+    }
+    HIPC(ctx, hipMemcpyAsync(g->cx, cx, sizeof(float) * nx, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(g->cy, cy, sizeof(float) * ny, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(g->cz, cz, sizeof(float) * nz, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    *out = g;
+    return WA_OK;
+}
+
+static int grid_count_free(wa_grid *g)
+{
+    wa_ctx *ctx = g->ctx;
+    unsigned long long *d_cnt = nullptr, h = 0;
+    HIPC(ctx, hipMalloc((void **)&d_cnt, 8));
+    HIPC(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    k_count_free<<<1024, 256, 0, ctx->stream>>>(g->occ, g->d.n, d_cnt);
+    HIPC(ctx, hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_cnt);
+    g->n_free = (int64_t)h;
+    return WA_OK;
+}
+
+int wa_grid_from_mesh(wa_ctx *ctx, const float *tris, int64_t n_tris, float precision, int32_t wall,
+                      wa_grid **out, float *bbox6_out)
+{
+    if (!ctx || !tris || !out || n_tris <= 0 || !(precision > 0) || wall < 0) return fail(ctx, WA_ERR_ARG, "wa_grid_from_mesh: bad argument");
+    *out = nullptr;
+    // bbox over all vertices (model_grid_map.hpp:165-181) and the ranges (:198-200)
+    float mn[3] = {tris[3], tris[4], tris[5]}, mx[3] = {tris[3], tris[4], tris[5]};
+    for (int64_t t = 0; t < n_tris; t++)
+        for (int v = 0; v < 3; v++)
+            for (int c = 0; c < 3; c++) {
+                float q = tris[t * 12 + 3 + v * 3 + c];
+                mx[c] = q > mx[c] ? q : mx[c];
+                mn[c] = q < mn[c] ? q : mn[c];
+            }
+    int32_t dims[3];
+    for (int c = 0; c < 3; c++) dims[c] = (int)((mx[c] - mn[c]) / precision) + 1 + 2 * wall;
+    if (bbox6_out) for (int c = 0; c < 3; c++) { bbox6_out[c] = mn[c]; bbox6_out[3 + c] = mx[c]; }
+    std::vector<float> ax[3];
+    for (int c = 0; c < 3; c++) {
+        if (dims[c] < 1) return fail(ctx, WA_ERR_ARG, "degenerate mesh extent");
+        ax[c].resize(dims[c]);
+        wa_axis_coords(mn[c], mx[c], precision, wall, dims[c], ax[c].data());
+    }
+    wa_grid *g = nullptr;
+    int rc = grid_alloc(ctx, dims[0], dims[1], dims[2], ax[0].data(), ax[1].data(), ax[2].data(), precision, wall, &g);
+    if (rc) return rc;
+    float *d_tris = nullptr;
+    if (dalloc(&d_tris, (size_t)n_tris * 12)) { wa_grid_destroy(g); return fail(ctx, WA_ERR_ALLOC, "triangle buffer"); }
+    HIPC(ctx, hipMemcpyAsync(d_tris, tris, sizeof(float) * 12 * n_tris, hipMemcpyHostToDevice, ctx->stream));
+    unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+    k_voxelize<<<blocks, 256, 0, ctx->stream>>>(d_tris, n_tris, precision, g->d, g->cx, g->cy, g->cz, g->occ);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_tris);
+    rc = grid_count_free(g);
+    if (rc) { wa_grid_destroy(g); return rc; }
+    *out = g;
+    return WA_OK;
+}
+
+int wa_grid_from_occupancy(wa_ctx *ctx, const uint8_t *free_, int32_t nx, int32_t ny, int32_t nz,
+                           const float *cx, const float *cy, const float *cz, float precision,
+                           int32_t wall, wa_grid **out)
+{
+    if (!ctx || !free_ || !cx || !cy || !cz || !out || !(precision > 0)) return fail(ctx, WA_ERR_ARG, "wa_grid_from_occupancy: bad argument");
+    *out = nullptr;
+    wa_grid *g = nullptr;
+    int rc = grid_alloc(ctx, nx, ny, nz, cx, cy, cz, precision, wall, &g);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(g->occ, free_, (size_t)g->d.n, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    rc = grid_count_free(g);
+    if (rc) { wa_grid_destroy(g); return rc; }
+    *out = g;
+    return WA_OK;
+}
+
+void wa_grid_destroy(wa_grid *g)
+{
+    if (!g) return;
+    hipFree(g->cx); hipFree(g->cy); hipFree(g->cz); hipFree(g->occ);
+    delete g;
+}
+int wa_grid_info(const wa_grid *g, int32_t dims3[3], float *precision, int32_t *wall, int64_t *n_free)
+{
+    if (!g) return WA_ERR_ARG;
+    if (dims3) { dims3[0] = g->d.nx; dims3[1] = g->d.ny; dims3[2] = g->d.nz; }
+    if (precision) *precision = g->precision;
+    if (wall) *wall = g->wall;
+    if (n_free) *n_free = g->n_free;
+    return WA_OK;
+}
+int wa_grid_read_occupancy(const wa_grid *g, uint8_t *free_out)
+{
+    if (!g || !free_out) return WA_ERR_ARG;
+    HIPC(g->ctx, hipMemcpy(free_out, g->occ, (size_t)g->d.n, hipMemcpyDeviceToHost));
+    return WA_OK;
+}
+int wa_grid_read_coords(const wa_grid *g, float *cx, float *cy, float *cz)
+{
+    if (!g) return WA_ERR_ARG;
+    if (cx) HIPC(g->ctx, hipMemcpy(cx, g->cx, sizeof(float) * g->d.nx, hipMemcpyDeviceToHost));
+    if (cy) HIPC(g->ctx, hipMemcpy(cy, g->cy, sizeof(float) * g->d.ny, hipMemcpyDeviceToHost));
+    if (cz) HIPC(g->ctx, hipMemcpy(cz, g->cz, sizeof(float) * g->d.nz, hipMemcpyDeviceToHost));
+    return WA_OK;
+}
+int wa_grid_resolve_points(const wa_grid *g, const float *pts_xyz, int32_t n_pts, int64_t *ids_out)
+{
+    if (!g || !pts_xyz || !ids_out || n_pts < 0) return WA_ERR_ARG;
+    if (n_pts == 0) return WA_OK;
+    wa_ctx *ctx = g->ctx;
+    float *d_pts = nullptr;
+    long long *d_ids = nullptr;
+    if (dalloc(&d_pts, (size_t)n_pts * 3) || dalloc(&d_ids, (size_t)n_pts)) return fail(ctx, WA_ERR_ALLOC, "resolve buffers");
+    HIPC(ctx, hipMemcpyAsync(d_pts, pts_xyz, sizeof(float) * 3 * n_pts, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(d_ids, 0xff, sizeof(long long) * n_pts, ctx->stream));  // -1
+    unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+    k_resolve_points<<<blocks, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
+    HIPC(ctx, hipGetLastError());
+    std::vector<long long> h(n_pts);
+    HIPC(ctx, hipMemcpyAsync(h.data(), d_ids, sizeof(long long) * n_pts, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t i = 0; i < n_pts; i++) ids_out[i] = h[i];
+    hipFree(d_pts);
+    hipFree(d_ids);
+    return WA_OK;
+}
+
+// ------------------------------------------------------------------ ACS
+void wa_acs_default_params(wa_acs_params *p)
+{
+    if (!p) return;
+    p->alpha = 1;            // ACSRank_3D.hpp:319
+    p->beta = 0.6f;          // :320
+    p->rho = 0.8f;           // :321
+    p->pheromone_0 = 1.f;    // :324
+    p->max_iteration = 150;  // :322
+    p->predict = 10.f;       // default argument of searchBestPathOfPoints :427
+    p->fixed_colony = 0;
+    p->rng_mode = WA_RNG_DEV;
+    p->seed = 1;
+}
+
+static int env_int(const char *name, int def)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
+
+int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                  int64_t path_capacity, wa_acs **out)
+{
+    if (!ctx || !grid || !out || n_slots < 1 || max_colony < 1) return fail(ctx, WA_ERR_ARG, "wa_acs_create: bad argument");
+    *out = nullptr;
+    wa_acs *s = new wa_acs();
+    memset(&s->D, 0, sizeof s->D);
+    s->ctx = ctx;
+    s->grid = grid;
+    s->n_slots = n_slots;
+    s->max_colony = max_colony;
+    s->n_active = 0;
+    s->begun = false;
+    s->gens_enqueued = 0;
+    s->prof = false;
+    s->prof_every = 1;
+    s->d_starts = s->d_ends = nullptr;
+    s->d_streams = nullptr;
+    for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
+    const int64_t n = grid->d.n;
+    if (path_capacity <= 0) path_capacity = n < (1 << 18) ? n : (1 << 18);
+    if (path_capacity > n) path_capacity = n;
+    if (path_capacity < 2) path_capacity = 2;
+    s->path_cap = path_capacity;
+    WaAcsDev &D = s->D;
+    D.d = grid->d;
+    D.cx = grid->cx; D.cy = grid->cy; D.cz = grid->cz; D.occ = grid->occ;
+    D.pher_stride = ((6 * n + 63) / 64) * 64;
+    D.path_cap = path_capacity;
+    D.vbits_words = (n + 31) / 32;
+    D.max_colony = max_colony;
+    D.trace_cap = 0;
+    int lg = 11;
+    while ((1 << lg) < 16 * (grid->d.nx + grid->d.ny + grid->d.nz) && lg < 13) lg++;
+    s->hash_log2 = env_int("WA_HASH_LOG2", lg);
+    if (s->hash_log2 < 6) s->hash_log2 = 6;
+    if (s->hash_log2 > 14) s->hash_log2 = 14;
+    s->evap_blocks = env_int("WA_EVAP_BLOCKS", 2048);
+    const size_t S = (size_t)n_slots, C = (size_t)max_colony;
+    hipError_t e = hipSuccess;
+    e = e ? e : dalloc(&D.pher, S * D.pher_stride);
+    e = e ? e : dalloc(&D.heur, S * D.pher_stride);
+    e = e ? e : dalloc(&D.mask, S * D.pher_stride);
+    e = e ? e : dalloc(&D.bestmark, S * n);
+    e = e ? e : dalloc(&D.bestpath, S * path_capacity);
+    e = e ? e : dalloc(&D.paths, S * C * path_capacity);
+    e = e ? e : dalloc(&D.antL, S * C);
+    e = e ? e : dalloc(&D.antLen, S * C);
+    e = e ? e : dalloc(&D.perm, S * C);
+    e = e ? e : dalloc(&D.depA, S * C);
+    e = e ? e : dalloc(&D.sortk, S * C * 2);
+    e = e ? e : dalloc(&D.vbits, S * C * D.vbits_words);
+    e = e ? e : dalloc(&D.ctl, S);
+    e = e ? e : dalloc(&D.rng, 1);
+    e = e ? e : dalloc(&s->d_starts, S);
+    e = e ? e : dalloc(&s->d_ends, S);
+    e = e ? e : dalloc(&s->d_streams, S);
+    if (e != hipSuccess) {
+        wa_acs_destroy(s);
+        return fail(ctx, WA_ERR_ALLOC, "wa_acs_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    HIPC(ctx, hipMemsetAsync(D.mask, 0, sizeof(unsigned long long) * S * D.pher_stride, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.heur, 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.pher, 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.bestmark, 0, sizeof(uint32_t) * S * n, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.vbits, 0, sizeof(uint32_t) * S * C * D.vbits_words, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.ctl, 0, sizeof(WaSlotCtl) * S, ctx->stream));
+    WaGlibcRand r0;
+    wa_glibc_seed(&r0, 1);  // a process that never calls srand() behaves as srand(1)
+    HIPC(ctx, hipMemcpyAsync(D.rng, &r0, sizeof r0, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    *out = s;
+    int rc = wa_acs_init_pheromone(s, -1, 1.0f);
+    if (rc) { wa_acs_destroy(s); *out = nullptr; return rc; }
+    return WA_OK;
+}
+
+static void free_trace(wa_acs *s)
+{
+    hipFree(s->D.trBest); hipFree(s->D.trIter); hipFree(s->D.trColony); hipFree(s->D.trFinite); hipFree(s->D.trSteps);
+    s->D.trBest = s->D.trIter = nullptr;
+    s->D.trColony = s->D.trFinite = nullptr;
+    s->D.trSteps = nullptr;
+    s->D.trace_cap = 0;
+}
+
+void wa_acs_destroy(wa_acs *s)
+{
+    if (!s) return;
+    hipStreamSynchronize(s->ctx->stream);
+    for (auto &p : s->ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    WaAcsDev &D = s->D;
+    hipFree(D.pher); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath);
+    hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
+    hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng);
+    hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
+    free_trace(s);
+    delete s;
+}
+
+static int init_pher(wa_acs *s, int32_t slot, float p0, int mode)
+{
+    if (!s || slot >= s->n_slots || !(p0 >= 0)) return fail(s ? s->ctx : nullptr, WA_ERR_ARG, "pheromone init: bad argument");
+    int32_t slot0 = slot < 0 ? 0 : slot, cnt = slot < 0 ? s->n_slots : 1;
+    dim3 grid((unsigned)((s->D.d.n + 255) / 256), (unsigned)cnt);
+    k_init_pheromone<<<grid, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
+    HIPC(s->ctx, hipGetLastError());
+    return WA_OK;
+}
+int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float p0) { return init_pher(s, slot, p0, 0); }
+int wa_acs_reset_pheromone(wa_acs *s, int32_t slot, float p0) { return init_pher(s, slot, p0, 1); }
+
+int wa_acs_srand(wa_acs *s, uint32_t seed)
+{
+    if (!s) return WA_ERR_ARG;
+    WaGlibcRand r;
+    wa_glibc_seed(&r, seed);
+    HIPC(s->ctx, hipMemcpyAsync(s->D.rng, &r, sizeof r, hipMemcpyHostToDevice, s->ctx->stream));
+    HIPC(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    return WA_OK;
+}
+int wa_acs_rand_state(wa_acs *s, int32_t st[36], int32_t set)
+{
+    if (!s || !st) return WA_ERR_ARG;
+    WaGlibcRand r;
+    if (set) {
+        memcpy(r.r, st, sizeof(int32_t) * 34);
+        r.f = st[34];
+        r.b = st[35];
+        HIPC(s->ctx, hipMemcpyAsync(s->D.rng, &r, sizeof r, hipMemcpyHostToDevice, s->ctx->stream));
+        HIPC(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    } else {
+        HIPC(s->ctx, hipStreamSynchronize(s->ctx->stream));
+        HIPC(s->ctx, hipMemcpy(&r, s->D.rng, sizeof r, hipMemcpyDeviceToHost));
+        memcpy(st, r.r, sizeof(int32_t) * 34);
+        st[34] = r.f;
+        st[35] = r.b;
+    }
+    return WA_OK;
+}
+
+int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const int64_t *start_ids,
+                 const int64_t *end_ids, const uint32_t *streams)
+{
+    if (!s || !p || !start_ids || !end_ids) return fail(s ? s->ctx : nullptr, WA_ERR_ARG, "wa_acs_begin: null argument");
+    wa_ctx *ctx = s->ctx;
+    if (n_problems < 1 || n_problems > s->n_slots) return fail(ctx, WA_ERR_ARG, "wa_acs_begin: n_problems exceeds the solver's slots");
+    if (p->rng_mode != WA_RNG_REF && p->rng_mode != WA_RNG_DEV) return fail(ctx, WA_ERR_ARG, "wa_acs_begin: rng_mode");
+    if (p->rng_mode == WA_RNG_REF && n_problems != 1)
+        return fail(ctx, WA_ERR_ARG, "wa_acs_begin: REF mode shares one libc stream, so problems run one at a time");
+    if (p->max_iteration < 0 || !(p->rho > 0) || !(p->pheromone_0 >= 0) || p->alpha < 0)
+        return fail(ctx, WA_ERR_ARG, "wa_acs_begin: parameter out of range");
+    for (int32_t i = 0; i < n_problems; i++) {
+        if (start_ids[i] < 0 || end_ids[i] < 0) return fail(ctx, WA_ERR_POINT, "wa_acs_begin: unresolved route point");
+        if (start_ids[i] >= s->D.d.n || end_ids[i] >= s->D.d.n) return fail(ctx, WA_ERR_ARG, "wa_acs_begin: voxel id out of range");
+    }
+    WaRun &R = s->R;
+    R.alpha = p->alpha; R.beta = p->beta; R.rho = p->rho; R.pheromone_0 = p->pheromone_0;
+    R.predict = p->predict; R.precision = s->grid->precision; R.fixed_colony = p->fixed_colony;
+    R.rng_mode = p->rng_mode; R.seed = p->seed;
+    // largest colony this run can reach: min(best.L, predict) <= predict (:247)
+    int32_t bound = p->fixed_colony > 0 ? p->fixed_colony : (int32_t)(0.35 * (double)p->predict / (double)R.precision);
+    if (bound > s->max_colony) return fail(ctx, WA_ERR_CAPACITY, "wa_acs_begin: colony exceeds max_colony of the solver");
+    s->colony_bound = bound < 0 ? 0 : bound;
+    if (p->max_iteration > s->D.trace_cap) {
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        free_trace(s);
+        size_t T = (size_t)s->n_slots * p->max_iteration;
+        if (dalloc(&s->D.trBest, T) || dalloc(&s->D.trIter, T) || dalloc(&s->D.trColony, T) ||
+            dalloc(&s->D.trFinite, T) || dalloc(&s->D.trSteps, T))
+            return fail(ctx, WA_ERR_ALLOC, "trace buffers");
+        s->D.trace_cap = p->max_iteration;
+    }
+    std::vector<long long> hs(n_problems), he(n_problems);
+    std::vector<uint32_t> hst(n_problems);
+    for (int32_t i = 0; i < n_problems; i++) { hs[i] = start_ids[i]; he[i] = end_ids[i]; hst[i] = streams ? streams[i] : (uint32_t)i; }
+    HIPC(ctx, hipMemcpyAsync(s->d_starts, hs.data(), sizeof(long long) * n_problems, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(s->d_ends, he.data(), sizeof(long long) * n_problems, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(s->d_streams, hst.data(), sizeof(uint32_t) * n_problems, hipMemcpyHostToDevice, ctx->stream));
+    k_begin<<<(n_problems + 63) / 64, 64, 0, ctx->stream>>>(s->D, R, n_problems, s->d_starts, s->d_ends, s->d_streams);
+    dim3 hg((unsigned)((s->D.d.n + 255) / 256), (unsigned)n_problems);
+    k_heuristic<<<hg, 256, 0, ctx->stream>>>(s->D, R.beta);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
+    s->n_active = n_problems;
+    s->begun = true;
+    s->gens_enqueued = 0;
+    return WA_OK;
+}
+
+static EvPair *prof_open(wa_acs *s, int cls, bool sampled)
+{
+    if (!sampled) return nullptr;
+    EvPair p;
+    p.cls = cls;
+    if (hipEventCreate(&p.a) != hipSuccess) return nullptr;
+    if (hipEventCreate(&p.b) != hipSuccess) { hipEventDestroy(p.a); return nullptr; }
+    hipEventRecord(p.a, s->ctx->stream);
+    s->ev.push_back(p);
+    return &s->ev.back();
+}
+static void prof_close(wa_acs *s, EvPair *p)
+{
+    if (p) hipEventRecord(p->b, s->ctx->stream);
+}
+
+static void launch_evaporate(wa_acs *s, int32_t slot0, int32_t cnt, float rho)
+{
+    dim3 grid((unsigned)s->evap_blocks, (unsigned)cnt);
+    k_evaporate<<<grid, 256, 0, s->ctx->stream>>>(s->D.pher + (int64_t)slot0 * s->D.pher_stride, s->D.pher_stride,
+                                                   6 * s->D.d.n, rho);
+}
+
+int wa_acs_run(wa_acs *s, int32_t n_generations)
+{
+    if (!s || n_generations < 0) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    if (!s->begun) return fail(ctx, WA_ERR_STATE, "wa_acs_run before wa_acs_begin");
+    const int32_t P = s->n_active;
+    const size_t shmem = sizeof(int32_t) << s->hash_log2;
+    const int32_t dep_bound = (int32_t)(0.2 * s->colony_bound) + 1;
+    const int32_t chunks = (dep_bound + 63) / 64;
+    for (int32_t g = 0; g < n_generations; g++) {
+        const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
+        EvPair *e = prof_open(s, WA_K_WALK, sampled);
+        if (s->R.rng_mode == WA_RNG_DEV) {
+            if (s->colony_bound > 0) k_walk_dev<<<dim3((unsigned)s->colony_bound, (unsigned)P), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+        } else {
+            k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+        }
+        prof_close(s, e);
+        e = prof_open(s, WA_K_RANK, sampled);
+        k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
+        prof_close(s, e);
+        e = prof_open(s, WA_K_EVAPORATE, sampled);
+        launch_evaporate(s, 0, P, s->R.rho);
+        prof_close(s, e);
+        e = prof_open(s, WA_K_DEPOSIT, sampled);
+        for (int32_t c = 0; c < chunks; c++) {
+            dim3 dg(8, 64, (unsigned)P);
+            k_deposit_mark<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+            k_deposit_apply<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+        }
+        prof_close(s, e);
+        s->gens_enqueued++;
+    }
+    HIPC(ctx, hipGetLastError());
+    return WA_OK;
+}
+
+int wa_acs_sync(wa_acs *s)
+{
+    if (!s) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    // fold finished event pairs into the accumulators
+    for (auto &p : s->ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { s->prof_ms[p.cls] += ms; s->prof_n[p.cls]++; }
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    s->ev.clear();
+    if (s->begun && s->n_active > 0) {
+        std::vector<WaSlotCtl> c(s->n_active);
+        HIPC(ctx, hipMemcpy(c.data(), s->D.ctl, sizeof(WaSlotCtl) * s->n_active, hipMemcpyDeviceToHost));
+        for (auto &x : c) {
+            if (x.flags & WA_FLAG_PATH_OVERFLOW) return fail(ctx, WA_ERR_CAPACITY, "a walk outgrew path_capacity; results are not reference-exact");
+            if (x.flags & WA_FLAG_COLONY_OVERFLOW) return fail(ctx, WA_ERR_CAPACITY, "colony exceeded max_colony");
+        }
+    }
+    return WA_OK;
+}
+
+int wa_acs_solve(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const int64_t *start_ids,
+                 const int64_t *end_ids, const uint32_t *streams)
+{
+    int rc = wa_acs_begin(s, p, n_problems, start_ids, end_ids, streams);
+    if (rc) return rc;
+    rc = wa_acs_run(s, p->max_iteration);
+    if (rc) return rc;
+    return wa_acs_sync(s);
+}
+
+int wa_acs_result(wa_acs *s, int32_t slot, float *cost, int64_t *len, int32_t *path_ids, int8_t *choices, int64_t cap)
+{
+    if (!s || slot < 0 || slot >= s->n_slots) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    if (!s->begun) return fail(ctx, WA_ERR_STATE, "no solve has run");
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    WaSlotCtl c;
+    HIPC(ctx, hipMemcpy(&c, s->D.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
+    if (cost) *cost = c.bestL;
+    int64_t n = isinf(c.bestL) ? 0 : c.best_len;
+    if (len) *len = n;
+    if ((path_ids || choices) && n > 0) {
+        if (cap < n) return fail(ctx, WA_ERR_CAPACITY, "wa_acs_result: output capacity too small");
+        std::vector<int32_t> w(n);
+        HIPC(ctx, hipMemcpy(w.data(), s->D.bestpath + (int64_t)slot * s->D.path_cap, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            if (path_ids) path_ids[i] = w[i] & (int32_t)WA_ID_MASK;
+            if (choices && i > 0) choices[i - 1] = (int8_t)((uint32_t)w[i] >> WA_K_SHIFT);
+        }
+    }
+    return WA_OK;
+}
+
+int wa_acs_trace(wa_acs *s, int32_t slot, int32_t *generations_done, float *best_L, float *iter_best_L,
+                 int32_t *colony, int32_t *finite, int64_t *steps)
+{
+    if (!s || slot < 0 || slot >= s->n_slots) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    if (!s->begun) return fail(ctx, WA_ERR_STATE, "no solve has run");
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t g = s->gens_enqueued < s->D.trace_cap ? s->gens_enqueued : s->D.trace_cap;
+    if (generations_done) *generations_done = g;
+    int64_t off = (int64_t)slot * s->D.trace_cap;
+    if (g > 0) {
+        if (best_L) HIPC(ctx, hipMemcpy(best_L, s->D.trBest + off, sizeof(float) * g, hipMemcpyDeviceToHost));
+        if (iter_best_L) HIPC(ctx, hipMemcpy(iter_best_L, s->D.trIter + off, sizeof(float) * g, hipMemcpyDeviceToHost));
+        if (colony) HIPC(ctx, hipMemcpy(colony, s->D.trColony + off, sizeof(int32_t) * g, hipMemcpyDeviceToHost));
+        if (finite) HIPC(ctx, hipMemcpy(finite, s->D.trFinite + off, sizeof(int32_t) * g, hipMemcpyDeviceToHost));
+        if (steps) HIPC(ctx, hipMemcpy(steps, s->D.trSteps + off, sizeof(int64_t) * g, hipMemcpyDeviceToHost));
+    }
+    return WA_OK;
+}
+
+int wa_acs_export_trace(wa_acs *s, void *dst_device, int32_t gen0, int32_t count)
+{
+    if (!s || !dst_device || gen0 < 0 || count < 1) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    if (!s->begun || gen0 + count > s->D.trace_cap) return fail(ctx, WA_ERR_STATE, "wa_acs_export_trace: range not recorded");
+    HIPC(ctx, hipMemcpy2DAsync(dst_device, sizeof(float) * count, s->D.trBest + gen0, sizeof(float) * s->D.trace_cap,
+                               sizeof(float) * count, (size_t)s->n_active, hipMemcpyDeviceToDevice, ctx->stream));
+    return WA_OK;
+}
+
+int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out)
+{
+    if (!s || !out || slot < 0 || slot >= s->n_slots) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = 6 * s->D.d.n;
+    HIPC(ctx, hipMemcpy(out, s->D.pher + (int64_t)slot * s->D.pher_stride, sizeof(float) * m, hipMemcpyDeviceToHost));
+    uint32_t *u = (uint32_t *)out;
+    for (int64_t i = 0; i < m; i++) u[i] &= 0x7fffffffu;  // drop the admissibility bit
+    return WA_OK;
+}
+
+int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, float *Q)
+{
+    if (!s || slot < 0 || slot >= s->n_slots) return WA_ERR_ARG;
+    wa_ctx *ctx = s->ctx;
+    if (!s->begun || s->gens_enqueued < 1) return fail(ctx, WA_ERR_STATE, "no generation has run");
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    WaSlotCtl c;
+    HIPC(ctx, hipMemcpy(&c, s->D.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
+    int32_t g = s->gens_enqueued - 1;
+    if (colony && g < s->D.trace_cap) HIPC(ctx, hipMemcpy(colony, s->D.trColony + (int64_t)slot * s->D.trace_cap + g, 4, hipMemcpyDeviceToHost));
+    if (lambda) *lambda = c.dep_lambda;
+    if (Q) *Q = c.dep_Q;
+    return WA_OK;
+}
+
+int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every)
+{
+    if (!s) return WA_ERR_ARG;
+    s->prof = enable != 0;
+    s->prof_every = sample_every > 0 ? sample_every : 1;
+    for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
+    return WA_OK;
+}
+int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT])
+{
+    if (!s) return WA_ERR_ARG;
+    int rc = wa_acs_sync(s);
+    for (int i = 0; i < WA_K_COUNT; i++) {
+        if (ms) ms[i] = s->prof_ms[i];
+        if (launches) launches[i] = s->prof_n[i];
+    }
+    return rc;
+}
+int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats)
+{
+    if (!s || slot < 0 || slot >= s->n_slots || repeats < 1) return WA_ERR_ARG;
+    for (int32_t r = 0; r < repeats; r++) {
+        EvPair *e = prof_open(s, WA_K_EVAPORATE, s->prof);
+        launch_evaporate(s, slot, 1, rho);
+        prof_close(s, e);
+    }
+    HIPC(s->ctx, hipGetLastError());
+    return WA_OK;
+}
+
+// ------------------------------------------------------------------ GTSP
+int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32_t n_instances,
+                  const wa_gtsp_params *p, int32_t *rand_state36, int32_t *tour_edges,
+                  double *tour_cost, int32_t *iterations, double *pheromone_out)
+{
+    if (!ctx || !dist || !p || !tour_edges || n < 2 || n_instances < 1) return fail(ctx, WA_ERR_ARG, "wa_gtsp_solve: bad argument");
+    if (p->rng_mode == WA_RNG_REF && n_instances != 1) return fail(ctx, WA_ERR_ARG, "wa_gtsp_solve: REF mode runs one instance");
+    const size_t I = (size_t)n_instances, nn = (size_t)n * n;
+    WaGtspDev G;
+    memset(&G, 0, sizeof G);
+    double *d_dist = nullptr;
+    hipError_t e = hipSuccess;
+    e = e ? e : dalloc(&d_dist, I * nn);
+    e = e ? e : dalloc(&G.pher, I * nn);
+    e = e ? e : dalloc(&G.h6, I * nn);
+    e = e ? e : dalloc(&G.info, I * nn);
+    e = e ? e : dalloc(&G.antL, I * n);
+    e = e ? e : dalloc(&G.tours, I * nn * 2);
+    e = e ? e : dalloc(&G.best, I * n * 2);
+    e = e ? e : dalloc(&G.inJ, I * nn);
+    e = e ? e : dalloc(&G.rbuf, nn);
+    e = e ? e : dalloc(&G.rng, 1);
+    e = e ? e : dalloc(&G.out_cost, I);
+    e = e ? e : dalloc(&G.out_iters, I);
+    auto cleanup = [&]() {
+        hipFree(d_dist); hipFree(G.pher); hipFree(G.h6); hipFree(G.info); hipFree(G.antL); hipFree(G.tours);
+        hipFree(G.best); hipFree(G.inJ); hipFree(G.rbuf); hipFree(G.rng); hipFree(G.out_cost); hipFree(G.out_iters);
+    };
+    if (e != hipSuccess) { cleanup(); return fail(ctx, WA_ERR_ALLOC, "wa_gtsp_solve: %s", hipGetErrorString(e)); }
+    G.dist = d_dist;
+    G.n = n; G.cnt = cnt; G.max_iterations = p->max_iterations; G.rng_mode = p->rng_mode;
+    G.seed = p->seed; G.stream0 = p->stream;
+    WaGlibcRand r;
+    if (rand_state36) { memcpy(r.r, rand_state36, sizeof(int32_t) * 34); r.f = rand_state36[34]; r.b = rand_state36[35]; }
+    else wa_glibc_seed(&r, 1);
+    hipError_t h = hipMemcpyAsync(d_dist, dist, sizeof(double) * I * nn, hipMemcpyHostToDevice, ctx->stream);
+    h = h ? h : hipMemcpyAsync(G.rng, &r, sizeof r, hipMemcpyHostToDevice, ctx->stream);
+    h = h ? h : hipMemsetAsync(G.best, 0, sizeof(int32_t) * I * n * 2, ctx->stream);
+    if (h == hipSuccess) {
+        k_gtsp<<<(unsigned)n_instances, 256, 0, ctx->stream>>>(G);
+        h = hipGetLastError();
+    }
+    std::vector<double> cost(I);
+    std::vector<int32_t> its(I);
+    h = h ? h : hipMemcpyAsync(tour_edges, G.best, sizeof(int32_t) * I * n * 2, hipMemcpyDeviceToHost, ctx->stream);
+    h = h ? h : hipMemcpyAsync(cost.data(), G.out_cost, sizeof(double) * I, hipMemcpyDeviceToHost, ctx->stream);
+    h = h ? h : hipMemcpyAsync(its.data(), G.out_iters, sizeof(int32_t) * I, hipMemcpyDeviceToHost, ctx->stream);
+    h = h ? h : hipMemcpyAsync(&r, G.rng, sizeof r, hipMemcpyDeviceToHost, ctx->stream);
+    if (pheromone_out) h = h ? h : hipMemcpyAsync(pheromone_out, G.pher, sizeof(double) * I * nn, hipMemcpyDeviceToHost, ctx->stream);
+    h = h ? h : hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (h != hipSuccess) return fail(ctx, WA_ERR_DEVICE, "wa_gtsp_solve: %s", hipGetErrorString(h));
+    for (size_t i = 0; i < I; i++) {
+        if (tour_cost) tour_cost[i] = cost[i];
+        if (iterations) iterations[i] = its[i];
+    }
+    if (rand_state36 && p->rng_mode == WA_RNG_REF) { memcpy(rand_state36, r.r, sizeof(int32_t) * 34); rand_state36[34] = r.f; rand_state36[35] = r.b; }
+    return WA_OK;
+}
+
+}  // extern "C"
