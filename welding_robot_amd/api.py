@@ -1,6 +1,7 @@
 """Thin numpy-facing wrappers over the C ABI (include/weldacs.h) for tests and bench.py.
 All compute happens in libweldacs.so's HIP kernels; this file only marshals pointers."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -20,6 +21,7 @@ class Context:
         if rc:
             raise WeldacsError(rc, "wa_ctx_create(%d) failed: no usable HIP device" % device)
         self.h = h
+        self._children = weakref.WeakSet()  # grids / solvers must be destroyed before the context
 
     def check(self, rc):
         if rc:
@@ -27,6 +29,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ch in sorted(list(self._children), key=lambda o: 0 if isinstance(o, AcsSolver) else 1):
+                ch.close()
             self.lib.wa_ctx_destroy(self.h)
             self.h = None
 
@@ -77,6 +81,7 @@ def axis_coords(lo, hi, precision, wall, n):
 class Grid:
     def __init__(self, ctx, handle, bbox=None):
         self.ctx, self.h, self.bbox = ctx, handle, bbox
+        ctx._children.add(self)
         dims = np.zeros(3, np.int32)
         p, w, nf = C.c_float(), C.c_int32(), C.c_int64()
         ctx.check(ctx.lib.wa_grid_info(self.h, _ptr(dims), C.byref(p), C.byref(w), C.byref(nf)))
@@ -145,6 +150,7 @@ class AcsSolver:
         ctx.check(ctx.lib.wa_acs_create(ctx.h, grid.h, n_slots, max_colony, path_capacity, C.byref(h)))
         self.h = h
         self.iters = 0
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None):
