@@ -71,12 +71,25 @@ uint64_t wo_splitmix64(uint64_t *state)
 }
 
 /* DEV-mode random integer: a pure function of (seed, stream, generation, ant, step), so
- * every ant of every problem can walk in parallel.  Same formula as csrc/acs_common.h. */
-uint32_t wo_ctr_rand31(uint64_t seed, uint32_t stream, uint32_t gen, uint32_t ant, uint32_t step)
+ * every ant of every problem can walk in parallel.  Same formula as csrc/wa_device.h. */
+static uint64_t ctr_antkey(uint64_t seed, uint32_t stream, uint32_t gen, uint32_t ant)
 {
     uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * (((uint64_t)stream << 32) | gen));
-    uint64_t v = mix64(k + 0x9E3779B97F4A7C15ULL * ((((uint64_t)ant << 32) | step) + 1));
-    return (uint32_t)(v >> 33);
+    return mix64(k + 0x9E3779B97F4A7C15ULL * ((uint64_t)ant + 1));
+}
+static uint32_t ctr_draw(uint64_t antkey, uint32_t step)
+{
+    uint32_t x = ((uint32_t)antkey + step * 0x9E3779B9u) ^ (uint32_t)(antkey >> 32);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >> 1;
+}
+uint32_t wo_ctr_rand31(uint64_t seed, uint32_t stream, uint32_t gen, uint32_t ant, uint32_t step)
+{
+    return ctr_draw(ctr_antkey(seed, stream, gen, ant), step);
 }
 
 /* ================================================================== std::sort ====== */

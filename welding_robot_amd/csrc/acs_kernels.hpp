@@ -127,8 +127,16 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 // ------------------------------------------------------------------ the walk
+// One wavefront = one ant.  Lanes 0..5 own the six neighbours (edge order of :355-365); the
+// wave is alone on its SIMD most of the time, so the inner loop is written for instruction
+// count, not occupancy: no divergent branches on the fast path, the two ORDERED float sums of
+// selectNext (forward `total` :155, reverse `prob_sum` :177) are 5-step DPP row scans, the
+// roulette pick is one compare + ballot + find-last-bit, and the tabu probe's terminating
+// empty slot doubles as the insertion slot of the chosen neighbour.
+//
 // tabu set = open-addressing hash of voxel ids in LDS (the reference's std::set, :70,:145);
-// when a walk outgrows 3/4 of the table the wave spills to its private global bitmap.
+// when a walk outgrows 3/4 of the table the wave spills to its private global bitmap and
+// continues in the generic (slow) loop.
 struct WaTabu {
     int32_t *tab;
     uint32_t mask, shift;
@@ -161,14 +169,211 @@ __device__ __forceinline__ void tabu_insert(const WaTabu &t, int32_t key)
     t.tab[h] = key;
 }
 
+// lane i <- lane i-1 (row_shr:1) / lane i <- lane i+1 (row_shl:1); lanes shifted in read 0
+__device__ __forceinline__ float dpp_from_below(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_above(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));
+}
+
+struct WaWalkState {
+    int32_t cur, len;
+    uint32_t step;
+    float L;
+    bool done;
+};
+
+// fast path: hash tabu only.  Returns with st.done set, or with st.done clear when the table
+// reached its spill threshold (the caller continues in wa_walk_slow).
+//
+// Path words are not stored one per step: a global store per step would put the store's
+// round trip on the critical path (CDNA4 counts stores in vmcnt and the data VGPR cannot be
+// reused before the store retires).  Instead lane (len & 63) captures the word in a VGPR and
+// the wave flushes 64 consecutive path entries with ONE coalesced 256-byte store.
+template <int MODE>
+__device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__restrict__ pher,
+                                             const float *__restrict__ heur, int32_t *__restrict__ path,
+                                             int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t path_cap,
+                                             int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
+                                             int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out)
+{
+    const int lane = threadIdx.x;
+    const bool act = lane < 6;
+    const int32_t dk = wa_delta(lane, nx, nxy);
+    const uint32_t hmask = (1u << hash_log2) - 1u, hshift = 32 - hash_log2;
+    const bool alpha1 = R.alpha == 1;
+    const char *pher_b = reinterpret_cast<const char *>(pher);
+    const char *heur_b = reinterpret_cast<const char *>(heur);
+    int32_t cur = st.cur, len = st.len;
+    uint32_t step = st.step;
+    float L = st.L;
+    int32_t pbuf = st.cur;   // lane (i & 63) holds path word i of the current 64-entry block
+    int32_t pflush = 0;
+    for (;;) {
+        // ---- one neighbour per lane: pheromone (sign = static admissibility), heuristic, tabu probe
+        float p = -0.f, h = 0.f;
+        const int32_t nb = cur + dk;
+        uint32_t hs = ((uint32_t)nb * 2654435761u) >> hshift;
+        int32_t tv = WA_HASH_EMPTY;
+        if (act) {
+            const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)lane) * 4u;  // < 4 GiB (checked at create)
+            p = *reinterpret_cast<const float *>(pher_b + boff);
+            h = *reinterpret_cast<const float *>(heur_b + boff);
+            tv = tab[hs];
+        }
+        bool unresolved = tv != nb && tv != WA_HASH_EMPTY;
+        while (__ballot(unresolved)) {  // collisions only
+            if (unresolved) {
+                hs = (hs + 1) & hmask;
+                tv = tab[hs];
+                unresolved = tv != nb && tv != WA_HASH_EMPTY;
+            }
+        }
+        const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
+        const uint32_t m = (uint32_t)__ballot(adm);
+        if (m == 0) { L = INFINITY; st.done = true; break; }                  // :162-166, no draw
+        const float info = (alpha1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
+        const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
+        // total = ((((0 + a0) + a1) + ...) + a5)   (:155)   -> lane 5
+        float t = 0.f + a;
+#pragma unroll
+        for (int i = 0; i < 5; i++) t = dpp_from_below(t) + a;
+        const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 5));
+        // prob_sum after adding candidate i, accumulated from i = 5 downwards (:172-177) -> lane i
+        float c = 0.f + a;
+#pragma unroll
+        for (int i = 0; i < 5; i++) c = dpp_from_above(c) + a;
+        int32_t r;
+        if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
+        else r = wa_glibc_next(rng_r, rng_f, rng_b);  // every lane advances its own copy in lockstep
+        float rnd = (float)r / 2147483648.0f;          // (float)RAND_MAX == 2^31 (:169)
+        rnd *= total;                                  // :170
+        const uint32_t m2 = (uint32_t)__ballot(adm && c >= rnd);  // :178
+        if (m2 == 0) { L = INFINITY; st.done = true; break; }     // :191-192
+        const int pick = 31 - __clz((int)m2);          // first hit when scanning i = 5..0
+        const int32_t next = cur + __builtin_amdgcn_readlane(dk, pick);  // lane k holds delta_k
+        if (len >= path_cap) {
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+            L = INFINITY;
+            st.done = true;
+            break;
+        }
+        if (lane == pick) tab[hs] = nb;                // addNextNode :75 -- the probe ended on the free slot
+        pbuf = (lane == (len & 63)) ? (next | (pick << WA_K_SHIFT)) : pbuf;  // :76-77
+        if ((len & 63) == 63) {                        // block full: one coalesced store
+            pflush = pbuf;
+            path[(len & ~63) + lane] = pflush;
+        }
+        len++;
+        L += R.precision;                              // :78, distance == precision (:378)
+        step++;
+        if (next == end) { st.done = true; break; }    // :182-186
+        cur = next;
+        if (len > spill_at) break;
+    }
+    if (len & 63) {  // partial last block (entries [len & ~63, len))
+        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
+    }
+    st.cur = cur; st.len = len; st.step = step; st.L = L;
+}
+
+// generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
+template <int MODE>
+__device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, const float *pher, const float *heur,
+                                          int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t *rng_r,
+                                          int32_t &rng_f, int32_t &rng_b, int32_t spill_at, WaWalkState &st,
+                                          int32_t *flags_out)
+{
+    const int lane = threadIdx.x;
+    const int32_t nx = D.d.nx, nxy = D.d.nxy;
+    int32_t cur = st.cur, len = st.len;
+    uint32_t step = st.step;
+    float L = st.L;
+    const int k = lane;
+    const int32_t dk = wa_delta(k, nx, nxy);
+    for (;;) {
+        if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
+            __threadfence();
+            for (int i = lane; i < len; i += 64) {
+                int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
+                uint32_t old = atomicOr(&T.bits[(uint32_t)id >> 5], 1u << (id & 31));
+                asm volatile("" ::"v"(old));
+            }
+            __threadfence();
+            T.spilled = true;
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_BITMAP_USED);
+        }
+        float p = -0.f, h = 0.f;
+        bool adm = false;
+        if (k < 6) {
+            p = pher[(int64_t)cur * 6 + k];
+            h = heur[(int64_t)cur * 6 + k];
+            if ((__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);
+        }
+        float info = wa_powi(fabsf(p), R.alpha) * h;
+        uint32_t m = (uint32_t)__ballot(adm) & 0x3fu;
+        if (m == 0) { L = INFINITY; break; }
+        float v[6];
+        float total = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
+            if ((m >> i) & 1u) total += v[i];
+        }
+        int32_t r;
+        if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
+        else r = wa_glibc_next(rng_r, rng_f, rng_b);
+        float rnd = (float)r / 2147483648.0f;
+        rnd *= total;
+        float prob = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            if (pick < 0 && ((m >> i) & 1u)) {
+                prob += v[i];
+                if (prob >= rnd) pick = i;
+            }
+        }
+        if (pick < 0) { L = INFINITY; break; }
+        int32_t next = cur + wa_delta(pick, nx, nxy);
+        if (len >= D.path_cap) {
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+            L = INFINITY;
+            break;
+        }
+        if (lane == 0) {
+            path[len] = next | (pick << WA_K_SHIFT);
+            tabu_insert(T, next);
+        }
+        __builtin_amdgcn_wave_barrier();
+        len++;
+        L += R.precision;
+        step++;
+        if (next == end) break;
+        cur = next;
+    }
+    if (T.spilled) {  // leave the bitmap all-zero for the next walk
+        __threadfence();
+        for (int i = lane; i < len; i += 64) {
+            int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
+            __hip_atomic_store(&T.bits[(uint32_t)id >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+    }
+    st.cur = cur; st.len = len; st.step = step; st.L = L;
+    st.done = true;
+}
+
 template <int MODE>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
-                                            int32_t start, int32_t end, uint64_t key, int32_t *tab,
+                                            int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
                                             int32_t *flags_out)
 {
     const int lane = threadIdx.x;
-    const int32_t nx = D.d.nx, nxy = D.d.nxy;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
@@ -180,93 +385,19 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
 
-    for (int i = lane; i <= (int)T.mask; i += 64) tab[i] = WA_HASH_EMPTY;
+    int4 *tab4 = reinterpret_cast<int4 *>(tab);
+    for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {  // addStartNode :81-86
-        path[0] = start;
-        tabu_insert(T, start);
-    }
+    if (lane == 0) tabu_insert(T, start);  // addStartNode :81-86 (path[0] is buffered by the fast loop)
     __builtin_amdgcn_wave_barrier();
-
-    int32_t cur = start, len = 1;
-    uint32_t step = 0;
-    float L = 0.f;
-    const int k = lane;
-    const int32_t dk = wa_delta(k, nx, nxy);
-    for (;;) {
-        // ---- lanes 0..5: one neighbour each (:142-159)
-        float p = -0.f, h = 0.f;
-        bool adm = false;
-        if (k < 6) {
-            p = pher[(int64_t)cur * 6 + k];
-            h = heur[(int64_t)cur * 6 + k];
-            if ((__float_as_uint(p) >> 31) == 0)      // in bounds and free (:148)
-                adm = !tabu_has(T, cur + dk);         // not yet visited (:145-146)
-        }
-        float info = wa_powi(fabsf(p), R.alpha) * h;  // :154
-        uint32_t m = (uint32_t)__ballot(adm) & 0x3fu;
-        if (m == 0) { L = INFINITY; break; }          // :162-166
-        float v[6];
-        float total = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
-            if ((m >> i) & 1u) total += v[i];         // :155, forward order
-        }
-        int32_t r;
-        if (MODE == 1) r = (int32_t)wa_ctr_draw(key, (uint32_t)ant, step);
-        else r = wa_glibc_next(rng_r, rng_f, rng_b);   // every lane advances its own copy in lockstep
-        float rnd = (float)r / 2147483648.0f;          // (float)RAND_MAX == 2^31 (:169)
-        rnd *= total;                                  // :170
-        float prob = 0.f;
-        int pick = -1;
-#pragma unroll
-        for (int i = 5; i >= 0; i--) {                 // reverse cumulative order (:172-189)
-            if (pick < 0 && ((m >> i) & 1u)) {
-                prob += v[i];
-                if (prob >= rnd) pick = i;
-            }
-        }
-        if (pick < 0) { L = INFINITY; break; }         // :191-192
-        int32_t next = cur + wa_delta(pick, nx, nxy);
-        if (len >= D.path_cap) {
-            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
-            L = INFINITY;
-            break;
-        }
-        if (lane == 0) {                               // addNextNode :73-79
-            path[len] = next | (pick << WA_K_SHIFT);
-            tabu_insert(T, next);
-        }
-        __builtin_amdgcn_wave_barrier();
-        len++;
-        L += R.precision;                              // distance == precision (:378)
-        step++;
-        if (next == end) break;                        // :182-186
-        cur = next;
-        if (!T.spilled && len > spill_at) {            // hash nearly full: move the set to the bitmap
-            __threadfence();
-            for (int i = lane; i < len; i += 64) {
-                int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
-                uint32_t old = atomicOr(&T.bits[(uint32_t)id >> 5], 1u << (id & 31));
-                asm volatile("" ::"v"(old));
-            }
-            __threadfence();
-            T.spilled = true;
-            if (lane == 0) atomicOr(flags_out, WA_FLAG_BITMAP_USED);
-        }
-    }
-    if (T.spilled) {  // leave the bitmap all-zero for the next walk
-        __threadfence();
-        for (int i = lane; i < len; i += 64) {
-            int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
-            __hip_atomic_store(&T.bits[(uint32_t)id >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __threadfence();
-    }
+    WaWalkState st;
+    st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
+    wa_walk_fast<MODE>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, rng_r, rng_f,
+                       rng_b, spill_at, st, flags_out);
+    if (!st.done) wa_walk_slow<MODE>(D, R, pher, heur, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
-        D.antL[(int64_t)slot * D.max_colony + ant] = L;
-        D.antLen[(int64_t)slot * D.max_colony + ant] = len;
+        D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
+        D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
     }
 }
 
@@ -278,9 +409,9 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const WaSlotCtl *c = &D.ctl[slot];
     if (ant >= c->colony) return;
     if (c->colony > D.max_colony) return;  // flagged by k_rank
-    uint64_t key = wa_ctr_key(R.seed, c->stream, (uint32_t)c->gen);
+    const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)c->gen), (uint32_t)ant);
     int32_t f = 0, b = 0;
-    wa_walk_one<1>(D, R, slot, ant, c->start, c->end, key, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+    wa_walk_one<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -292,8 +423,8 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     const WaSlotCtl *c = &D.ctl[slot];
     int32_t colony = c->colony;
     if (colony > D.max_colony) return;
-    // every lane keeps a private copy of the 31-word state in registers/scratch: all lanes draw
-    // in lockstep, so the copies stay identical and no cross-lane traffic is needed
+    // every lane keeps a private copy of the 31-word state: all lanes draw in lockstep, so the
+    // copies stay identical and no cross-lane traffic is needed
     int32_t r[31];
     for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
     int32_t f = D.rng->f, b = D.rng->b;

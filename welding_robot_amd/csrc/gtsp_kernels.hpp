@@ -84,12 +84,13 @@ __global__ __launch_bounds__(256) void k_gtsp(WaGtspDev G)
         const uint64_t key = wa_ctr_key(G.seed, G.stream0 + (uint32_t)inst, (uint32_t)it);
         for (int32_t k = tid; k < n; k += blockDim.x) {
             uint8_t *J = inJ + (int64_t)k * n;
+            const uint64_t antkey = wa_ctr_antkey(key, (uint32_t)k);
             int32_t r = k, left = n - 1;
             for (int32_t step = 0; step < n; step++) {
                 int32_t next = k;  // r1[k]
                 if (left > 0) {    // select_next :122-144
                     int32_t rv = G.rng_mode == 0 ? G.rbuf[step * n + k]
-                                                 : (int32_t)wa_ctr_draw(key, (uint32_t)k, (uint32_t)step);
+                                                 : (int32_t)wa_ctr_draw(antkey, (uint32_t)step);
                     double rnd = (double)rv / (double)2147483647;
                     const double *row = info + (int64_t)r * n;
                     double sum = 0, sp = 0;

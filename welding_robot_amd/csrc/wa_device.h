@@ -63,16 +63,27 @@ __host__ __device__ inline uint64_t wa_mix64(uint64_t z)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-// DEV-mode draw: pure function of (seed, stream, generation, ant, step); identical to
-// wo_ctr_rand31 in oracle/weld_oracle.c
+// DEV-mode draw: a pure function of (seed, stream, generation, ant, step) so that every ant of
+// every problem walks in parallel.  64-bit mixing once per generation and once per ant; the
+// per-step draw is a 32-bit avalanche hash (two multiplies) because it sits in the walk's
+// issue-bound inner loop.  Identical to wo_ctr_* in oracle/weld_oracle.c.
 __host__ __device__ inline uint64_t wa_ctr_key(uint64_t seed, uint32_t stream, uint32_t gen)
 {
     return wa_mix64(seed + 0x9E3779B97F4A7C15ULL * (((uint64_t)stream << 32) | gen));
 }
-__host__ __device__ inline uint32_t wa_ctr_draw(uint64_t key, uint32_t ant, uint32_t step)
+__host__ __device__ inline uint64_t wa_ctr_antkey(uint64_t key, uint32_t ant)
 {
-    uint64_t v = wa_mix64(key + 0x9E3779B97F4A7C15ULL * ((((uint64_t)ant << 32) | step) + 1));
-    return (uint32_t)(v >> 33);
+    return wa_mix64(key + 0x9E3779B97F4A7C15ULL * ((uint64_t)ant + 1));
+}
+__host__ __device__ inline uint32_t wa_ctr_draw(uint64_t antkey, uint32_t step)
+{
+    uint32_t x = ((uint32_t)antkey + step * 0x9E3779B9u) ^ (uint32_t)(antkey >> 32);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >> 1;  // 31 bits, like rand()
 }
 
 // glibc random_r TYPE_3 (stdlib/random_r.c): the stream behind the reference's rand()

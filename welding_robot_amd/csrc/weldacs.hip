@@ -346,6 +346,10 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->d_streams = nullptr;
     for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
     const int64_t n = grid->d.n;
+    if (24 * n >= (int64_t)1 << 32) {  // the walk addresses a slot's pheromone field with 32-bit byte offsets
+        delete s;
+        return fail(ctx, WA_ERR_ARG, "wa_acs_create: grids above 178,956,970 voxels are not supported");
+    }
     if (path_capacity <= 0) path_capacity = n < (1 << 18) ? n : (1 << 18);
     if (path_capacity > n) path_capacity = n;
     if (path_capacity < 2) path_capacity = 2;
