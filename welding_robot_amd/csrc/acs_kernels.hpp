@@ -193,18 +193,26 @@ struct WaWalkState {
 // round trip on the critical path (CDNA4 counts stores in vmcnt and the data VGPR cannot be
 // reused before the store retires).  Instead lane (len & 63) captures the word in a VGPR and
 // the wave flushes 64 consecutive path entries with ONE coalesced 256-byte store.
-template <int MODE>
+template <int MODE, bool ALPHA1>
 __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__restrict__ pher,
                                              const float *__restrict__ heur, int32_t *__restrict__ path,
-                                             int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t path_cap,
-                                             int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
+                                             int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
+                                             int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
                                              int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out)
 {
+    // Lane layout: group j = lane >> 3 (j < 6), role k2 = lane & 7 (k2 < 6).  Every step, group j
+    // PREFETCHES the pheromone/heuristic record of neighbour j of the current voxel (36 lanes x 2
+    // dwords); the group of the neighbour that gets picked then simply becomes the active group
+    // of the next step, so the record is already in the right lanes and the HBM / Infinity-Cache
+    // latency overlaps with this step's decision instead of following it.
     const int lane = threadIdx.x;
-    const bool act = lane < 6;
-    const int32_t dk = wa_delta(lane, nx, nxy);
+    const int j = lane >> 3, k2 = lane & 7;
+    const bool lane_ok = j < 6 && k2 < 6;
+    const int32_t dk = wa_delta(k2, nx, nxy);   // edge this lane evaluates when its group is active
+    const int32_t dj = wa_delta(j, nx, nxy);    // neighbour of `cur` this lane's group prefetches
+    const int32_t last_id = n_vox - 1;
+    const int32_t limit = path_cap < spill_at + 1 ? path_cap : spill_at + 1;  // leave the loop when len reaches it
     const uint32_t hmask = (1u << hash_log2) - 1u, hshift = 32 - hash_log2;
-    const bool alpha1 = R.alpha == 1;
     const char *pher_b = reinterpret_cast<const char *>(pher);
     const char *heur_b = reinterpret_cast<const char *>(heur);
     int32_t cur = st.cur, len = st.len;
@@ -212,18 +220,29 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     float L = st.L;
     int32_t pbuf = st.cur;   // lane (i & 63) holds path word i of the current 64-entry block
     int32_t pflush = 0;
+    int grp = 0;             // group holding the record of `cur`
+    float ublock = 0.f;      // DEV: lane i holds the uniform draw of step (step & ~63) + i
+    float pp = -0.f, ph = 0.f;
+    if (lane_ok && j == 0) {
+        const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
+        pp = *reinterpret_cast<const float *>(pher_b + boff);
+        ph = *reinterpret_cast<const float *>(heur_b + boff);
+    }
     for (;;) {
-        // ---- one neighbour per lane: pheromone (sign = static admissibility), heuristic, tabu probe
-        float p = -0.f, h = 0.f;
+        const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
+        const bool act = lane_ok && j == grp;
+        if (lane_ok) {                           // prefetch the six neighbours' records (clamped: an
+            int32_t pid = cur + dj;              // out-of-bounds neighbour is never walked to)
+            pid = pid < 0 ? 0 : (pid > last_id ? last_id : pid);
+            const uint32_t boff = ((uint32_t)pid * 6u + (uint32_t)k2) * 4u;  // < 4 GiB (checked at create)
+            pp = *reinterpret_cast<const float *>(pher_b + boff);
+            ph = *reinterpret_cast<const float *>(heur_b + boff);
+        }
+        // ---- one neighbour per active lane: sign of p = static admissibility, tabu probe in LDS
         const int32_t nb = cur + dk;
         uint32_t hs = ((uint32_t)nb * 2654435761u) >> hshift;
         int32_t tv = WA_HASH_EMPTY;
-        if (act) {
-            const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)lane) * 4u;  // < 4 GiB (checked at create)
-            p = *reinterpret_cast<const float *>(pher_b + boff);
-            h = *reinterpret_cast<const float *>(heur_b + boff);
-            tv = tab[hs];
-        }
+        if (act) tv = tab[hs];
         bool unresolved = tv != nb && tv != WA_HASH_EMPTY;
         while (__ballot(unresolved)) {  // collisions only
             if (unresolved) {
@@ -233,35 +252,34 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             }
         }
         const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
-        const uint32_t m = (uint32_t)__ballot(adm);
+        const unsigned long long m = __ballot(adm);
         if (m == 0) { L = INFINITY; st.done = true; break; }                  // :162-166, no draw
-        const float info = (alpha1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
+        const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
         const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
-        // total = ((((0 + a0) + a1) + ...) + a5)   (:155)   -> lane 5
+        // total = ((((0 + a0) + a1) + ...) + a5)   (:155)   -> role 5 of the active group
         float t = 0.f + a;
 #pragma unroll
         for (int i = 0; i < 5; i++) t = dpp_from_below(t) + a;
-        const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 5));
-        // prob_sum after adding candidate i, accumulated from i = 5 downwards (:172-177) -> lane i
+        const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), grp * 8 + 5));
+        // prob_sum after adding candidate i, accumulated from i = 5 downwards (:172-177) -> role i
         float c = 0.f + a;
 #pragma unroll
         for (int i = 0; i < 5; i++) c = dpp_from_above(c) + a;
-        int32_t r;
-        if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
-        else r = wa_glibc_next(rng_r, rng_f, rng_b);  // every lane advances its own copy in lockstep
-        float rnd = (float)r / 2147483648.0f;          // (float)RAND_MAX == 2^31 (:169)
-        rnd *= total;                                  // :170
-        const uint32_t m2 = (uint32_t)__ballot(adm && c >= rnd);  // :178
-        if (m2 == 0) { L = INFINITY; st.done = true; break; }     // :191-192
-        const int pick = 31 - __clz((int)m2);          // first hit when scanning i = 5..0
-        const int32_t next = cur + __builtin_amdgcn_readlane(dk, pick);  // lane k holds delta_k
-        if (len >= path_cap) {
-            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
-            L = INFINITY;
-            st.done = true;
-            break;
+        float rnd;                                     // (float)rand() / (float)RAND_MAX, RAND_MAX -> 2^31 (:169)
+        if (MODE == 1) {                               // DEV draws are pure functions of (ant, step):
+            if ((step & 63u) == 0)                     // 64 of them at a time, one per lane
+                ublock = (float)wa_ctr_draw(antkey, step + (uint32_t)lane) / 2147483648.0f;
+            rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), (int)(step & 63u)));
+        } else {
+            rnd = (float)wa_glibc_next(rng_r, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
         }
-        if (lane == pick) tab[hs] = nb;                // addNextNode :75 -- the probe ended on the free slot
+        rnd *= total;                                  // :170
+        const unsigned long long m2 = __ballot(adm && c >= rnd);  // :178
+        if (m2 == 0) { L = INFINITY; st.done = true; break; }     // :191-192
+        const int pick_lane = 63 - __clzll((long long)m2);        // first hit when scanning i = 5..0
+        const int pick = pick_lane - grp * 8;
+        const int32_t next = cur + __builtin_amdgcn_readlane(dk, pick);  // lane k (< 6) holds delta_k
+        if (lane == pick_lane) tab[hs] = nb;           // addNextNode :75 -- the probe ended on the free slot
         pbuf = (lane == (len & 63)) ? (next | (pick << WA_K_SHIFT)) : pbuf;  // :76-77
         if ((len & 63) == 63) {                        // block full: one coalesced store
             pflush = pbuf;
@@ -272,7 +290,13 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         step++;
         if (next == end) { st.done = true; break; }    // :182-186
         cur = next;
-        if (len > spill_at) break;
+        grp = pick;
+        if (len >= limit) break;                       // table 3/4 full or path buffer full
+    }
+    if (!st.done && len >= path_cap) {                 // the next step would not fit path[]
+        if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+        L = INFINITY;
+        st.done = true;
     }
     if (len & 63) {  // partial last block (entries [len & ~63, len))
         if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
@@ -367,7 +391,7 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
     st.done = true;
 }
 
-template <int MODE>
+template <int MODE, bool ALPHA1>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
@@ -392,7 +416,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     __builtin_amdgcn_wave_barrier();
     WaWalkState st;
     st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
-    wa_walk_fast<MODE>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, rng_r, rng_f,
+    wa_walk_fast<MODE, ALPHA1>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey, rng_r, rng_f,
                        rng_b, spill_at, st, flags_out);
     if (!st.done) wa_walk_slow<MODE>(D, R, pher, heur, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
@@ -402,6 +426,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
+template <bool ALPHA1>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2)
 {
     extern __shared__ int32_t lds[];
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     if (c->colony > D.max_colony) return;  // flagged by k_rank
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)c->gen), (uint32_t)ant);
     int32_t f = 0, b = 0;
-    wa_walk_one<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+    wa_walk_one<1, ALPHA1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -430,7 +455,7 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
+        wa_walk_one<0, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;

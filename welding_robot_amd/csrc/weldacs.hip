@@ -556,7 +556,11 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
         EvPair *e = prof_open(s, WA_K_WALK, sampled);
         if (s->R.rng_mode == WA_RNG_DEV) {
-            if (s->colony_bound > 0) k_walk_dev<<<dim3((unsigned)s->colony_bound, (unsigned)P), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+            if (s->colony_bound > 0) {
+                dim3 wg((unsigned)s->colony_bound, (unsigned)P);
+                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+            }
         } else {
             k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
         }
