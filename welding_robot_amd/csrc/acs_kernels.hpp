@@ -582,6 +582,9 @@ __device__ inline void wa_std_sort(WaRec *v, int32_t n)
 // ------------------------------------------------------------------ rank
 // one workgroup per problem: iteration best -> global best (strict <, first ant wins :263-264),
 // ranking (:273-275), per-rank deposit coefficient, trace, next generation's parameters.
+// The (L, ant) sort keys are staged in LDS (up to WA_RANK_LDS ants) so the counting rank reads
+// broadcast LDS words instead of a dependent chain of global loads.
+#define WA_RANK_LDS 2048
 __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
 {
     const int32_t slot = blockIdx.x, tid = threadIdx.x;
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
     const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
     int32_t *perm = D.perm + (int64_t)slot * D.max_colony;
     float *depA = D.depA + (int64_t)slot * D.max_colony;
+    __shared__ unsigned long long s_keys[WA_RANK_LDS];
     __shared__ unsigned long long s_min;
     __shared__ int32_t s_fin, s_ndep;
     __shared__ unsigned long long s_steps;
@@ -601,6 +605,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
         if (tid == 0) { atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW); ctl->gen = gen + 1; }
         return;
     }
+    const bool in_lds = colony <= WA_RANK_LDS;
     // L >= 0 or +inf, so the uint32 order of the bit pattern is the float order
     unsigned long long mykey = ~0ULL;
     int32_t myfin = 0;
@@ -608,19 +613,29 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
     for (int32_t a = tid; a < colony; a += blockDim.x) {
         float La = antL[a];
         unsigned long long key = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
+        if (in_lds) s_keys[a] = key;
         mykey = key < mykey ? key : mykey;
         myfin += (La != INFINITY) ? 1 : 0;
         mysteps += (unsigned long long)(antLen[a] - 1);
     }
-    atomicMin(&s_min, mykey);
-    atomicAdd(&s_fin, myfin);
-    atomicAdd(&s_steps, mysteps);
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long ok = __shfl_down(mykey, o, 64);
+        mykey = ok < mykey ? ok : mykey;
+        myfin += __shfl_down(myfin, o, 64);
+        mysteps += __shfl_down(mysteps, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        atomicMin(&s_min, mykey);
+        atomicAdd(&s_fin, myfin);
+        atomicAdd(&s_steps, mysteps);
+    }
     __syncthreads();
     float iterL = INFINITY;
     int32_t iterAnt = -1;
     if (colony > 0) { iterL = __uint_as_float((uint32_t)(s_min >> 32)); iterAnt = (int32_t)(s_min & 0xffffffffu); }
     float bestL = ctl->bestL;
     uint32_t ver = ctl->best_ver;
+    const float lambda = ctl->lambda, Q = ctl->Q;
     __syncthreads();
     if (iterAnt >= 0 && iterL < bestL) {  // best = agentK (:264): copy the path, re-stamp membership
         const int32_t blen = antLen[iterAnt];
@@ -639,31 +654,41 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
     // ---- ranking
     if (R.rng_mode == 1) {  // DEV: ascending (L, ant) by counting
         for (int32_t a = tid; a < colony; a += blockDim.x) {
-            unsigned long long ka = ((unsigned long long)__float_as_uint(antL[a]) << 32) | (uint32_t)a;
             int32_t r = 0;
-            for (int32_t b = 0; b < colony; b++) {
-                unsigned long long kb = ((unsigned long long)__float_as_uint(antL[b]) << 32) | (uint32_t)b;
-                r += kb < ka ? 1 : 0;
+            if (in_lds) {
+                const unsigned long long ka = s_keys[a];
+#pragma unroll 8
+                for (int32_t b = 0; b < colony; b++) r += s_keys[b] < ka ? 1 : 0;
+            } else {
+                const unsigned long long ka = ((unsigned long long)__float_as_uint(antL[a]) << 32) | (uint32_t)a;
+                for (int32_t b = 0; b < colony; b++) {
+                    unsigned long long kb = ((unsigned long long)__float_as_uint(antL[b]) << 32) | (uint32_t)b;
+                    r += kb < ka ? 1 : 0;
+                }
             }
             perm[r] = a;
+            // deposit coefficient of update_pheromone (:200,:211) for rank o = r + 1
+            const int32_t o = r + 1;
+            const float La = antL[a];
+            const bool ok = !(La == INFINITY || (float)o > lambda - 1);
+            depA[r] = ok ? (lambda - (float)o) * Q / La : 0.f;
+            if (ok) atomicMax(&s_ndep, o);
         }
-    } else if (tid == 0) {  // REF: libstdc++'s permutation
-        WaRec *rec = (WaRec *)(D.sortk + (int64_t)slot * D.max_colony * 2);
-        for (int32_t a = 0; a < colony; a++) { rec[a].k = antL[a]; rec[a].t = a; }
-        wa_std_sort(rec, colony);
-        for (int32_t a = 0; a < colony; a++) perm[a] = rec[a].t;
+    } else {
+        if (tid == 0) {  // REF: libstdc++'s permutation
+            WaRec *rec = (WaRec *)(D.sortk + (int64_t)slot * D.max_colony * 2);
+            for (int32_t a = 0; a < colony; a++) { rec[a].k = antL[a]; rec[a].t = a; }
+            wa_std_sort(rec, colony);
+            for (int32_t a = 0; a < colony; a++) perm[a] = rec[a].t;
+        }
+        __syncthreads();
+        for (int32_t o = 1 + tid; o <= colony; o += blockDim.x) {
+            float La = antL[perm[o - 1]];
+            bool ok = !(La == INFINITY || (float)o > lambda - 1);
+            depA[o - 1] = ok ? (lambda - (float)o) * Q / La : 0.f;
+            if (ok) atomicMax(&s_ndep, o);
+        }
     }
-    __syncthreads();
-    // ---- deposit coefficients of update_pheromone (:200,:211)
-    const float lambda = ctl->lambda, Q = ctl->Q;
-    int32_t myndep = 0;
-    for (int32_t o = 1 + tid; o <= colony; o += blockDim.x) {
-        float La = antL[perm[o - 1]];
-        bool ok = !(La == INFINITY || (float)o > lambda - 1);
-        depA[o - 1] = ok ? (lambda - (float)o) * Q / La : 0.f;
-        if (ok) myndep = o;
-    }
-    atomicMax(&s_ndep, myndep);
     __syncthreads();
     if (tid == 0) {
         if (gen < D.trace_cap) {
@@ -687,32 +712,37 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
 }
 
 // ------------------------------------------------------------------ evaporation (the HBM sweep)
-// :268-272 -- every edge of every voxel, occupied voxels and out-of-bounds edges included.
-// 48 B of traffic per voxel (24 read + 24 written).  float4 per lane, 4 independent float4
-// in flight per thread, grid-stride.
-__global__ __launch_bounds__(256) void k_evaporate(float *__restrict__ pher, int64_t stride, int64_t n_floats, float rho)
+// :268-272 -- every edge of every voxel, occupied voxels and out-of-bounds edges included:
+// dst = src * rho over 6N floats, 48 B of traffic per voxel (24 read + 24 written).  The
+// pheromone field is double-buffered so that this sweep (which only needs the field the walk
+// is READING) runs on a second stream concurrently with the latency-bound walk; src == dst is
+// allowed (in-place).  float4 per lane, 4 independent float4 in flight per thread, grid-stride.
+__global__ __launch_bounds__(256) void k_evaporate(const float *__restrict__ src_base, float *__restrict__ dst_base,
+                                                   int64_t stride, int64_t n_floats, float rho)
 {
-    float *base = pher + (int64_t)blockIdx.y * stride;
-    float4 *p4 = reinterpret_cast<float4 *>(base);
+    const float *src = src_base + (int64_t)blockIdx.y * stride;
+    float *dst = dst_base + (int64_t)blockIdx.y * stride;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
     const int64_t n4 = n_floats >> 2;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + 3 * gsz < n4; i += 4 * gsz) {
-        float4 a = p4[i], b = p4[i + gsz], c = p4[i + 2 * gsz], d = p4[i + 3 * gsz];
+        float4 a = s4[i], b = s4[i + gsz], c = s4[i + 2 * gsz], d = s4[i + 3 * gsz];
         a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
         b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
         c.x *= rho; c.y *= rho; c.z *= rho; c.w *= rho;
         d.x *= rho; d.y *= rho; d.z *= rho; d.w *= rho;
-        p4[i] = a; p4[i + gsz] = b; p4[i + 2 * gsz] = c; p4[i + 3 * gsz] = d;
+        d4[i] = a; d4[i + gsz] = b; d4[i + 2 * gsz] = c; d4[i + 3 * gsz] = d;
     }
     for (; i < n4; i += gsz) {
-        float4 a = p4[i];
+        float4 a = s4[i];
         a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
-        p4[i] = a;
+        d4[i] = a;
     }
     // tail (n_floats = 6N is even; at most 2 floats)
     int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_floats) base[t] *= rho;
+    if (t < n_floats) dst[t] = src[t] * rho;
 }
 
 // ------------------------------------------------------------------ ranked deposit

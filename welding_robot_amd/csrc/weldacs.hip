@@ -4,6 +4,7 @@
 #include "../../include/weldacs.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -20,7 +21,9 @@
 // ------------------------------------------------------------------ handles
 struct wa_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;    // main stream: every kernel except the overlapped evaporation sweep
+    hipStream_t stream2;   // evaporation sweep of generation g runs here, concurrently with walk g
+    hipEvent_t ev_fork, ev_join;
     std::string err;
     hipDeviceProp_t prop;
 };
@@ -39,7 +42,9 @@ struct wa_acs {
     const wa_grid *grid;
     int32_t n_slots, max_colony, n_active;
     int64_t path_cap;
-    WaAcsDev D;
+    WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
+    float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
+    int cur_buf;
     WaRun R;
     bool begun;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
@@ -88,7 +93,10 @@ int wa_ctx_create(int device_ordinal, wa_ctx **out)
     wa_ctx *c = new wa_ctx();
     c->device = device_ordinal;
     if (hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return WA_ERR_DEVICE;
     }
@@ -99,6 +107,9 @@ void wa_ctx_destroy(wa_ctx *c)
 {
     if (!c) return;
     hipStreamDestroy(c->stream);
+    hipStreamDestroy(c->stream2);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
     delete c;
 }
 const char *wa_last_error(const wa_ctx *c) { return c ? c->err.c_str() : "no context"; }
@@ -111,6 +122,7 @@ int wa_ctx_device_name(const wa_ctx *c, char *buf, size_t cap)
 int wa_ctx_sync(wa_ctx *c)
 {
     if (!c) return WA_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream2));
     HIPC(c, hipStreamSynchronize(c->stream));
     return WA_OK;
 }
@@ -344,6 +356,8 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->prof_every = 1;
     s->d_starts = s->d_ends = nullptr;
     s->d_streams = nullptr;
+    s->pher_buf[0] = s->pher_buf[1] = nullptr;
+    s->cur_buf = 0;
     for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
     const int64_t n = grid->d.n;
     if (24 * n >= (int64_t)1 << 32) {  // the walk addresses a slot's pheromone field with 32-bit byte offsets
@@ -370,7 +384,8 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->evap_blocks = env_int("WA_EVAP_BLOCKS", 2048);
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
-    e = e ? e : dalloc(&D.pher, S * D.pher_stride);
+    e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
+    e = e ? e : dalloc(&s->pher_buf[1], S * D.pher_stride);
     e = e ? e : dalloc(&D.heur, S * D.pher_stride);
     e = e ? e : dalloc(&D.mask, S * D.pher_stride);
     e = e ? e : dalloc(&D.bestmark, S * n);
@@ -393,7 +408,10 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     }
     HIPC(ctx, hipMemsetAsync(D.mask, 0, sizeof(unsigned long long) * S * D.pher_stride, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.heur, 0, sizeof(float) * S * D.pher_stride, ctx->stream));
-    HIPC(ctx, hipMemsetAsync(D.pher, 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    D.pher = s->pher_buf[0];
+    s->cur_buf = 0;
+    HIPC(ctx, hipMemsetAsync(s->pher_buf[0], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(s->pher_buf[1], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.bestmark, 0, sizeof(uint32_t) * S * n, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.vbits, 0, sizeof(uint32_t) * S * C * D.vbits_words, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.ctl, 0, sizeof(WaSlotCtl) * S, ctx->stream));
@@ -419,10 +437,11 @@ static void free_trace(wa_acs *s)
 void wa_acs_destroy(wa_acs *s)
 {
     if (!s) return;
+    hipStreamSynchronize(s->ctx->stream2);
     hipStreamSynchronize(s->ctx->stream);
     for (auto &p : s->ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     WaAcsDev &D = s->D;
-    hipFree(D.pher); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath);
+    hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
     hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
@@ -536,13 +555,32 @@ static void prof_close(wa_acs *s, EvPair *p)
     if (p) hipEventRecord(p->b, s->ctx->stream);
 }
 
-static void launch_evaporate(wa_acs *s, int32_t slot0, int32_t cnt, float rho)
+// dst = src * rho for `cnt` slots starting at slot0.  When `timed` the dispatch carries its own
+// start/stop events (hipExtLaunchKernelGGL): they stamp the kernel itself, not the stream gaps.
+static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float *dst, int32_t slot0, int32_t cnt, float rho, bool timed)
 {
     dim3 grid((unsigned)s->evap_blocks, (unsigned)cnt);
-    k_evaporate<<<grid, 256, 0, s->ctx->stream>>>(s->D.pher + (int64_t)slot0 * s->D.pher_stride, s->D.pher_stride,
-                                                   6 * s->D.d.n, rho);
+    const float *sp = src + (int64_t)slot0 * s->D.pher_stride;
+    float *dp = dst + (int64_t)slot0 * s->D.pher_stride;
+    if (timed) {
+        EvPair p;
+        p.cls = WA_K_EVAPORATE;
+        if (hipEventCreate(&p.a) == hipSuccess) {
+            if (hipEventCreate(&p.b) == hipSuccess) {
+                hipExtLaunchKernelGGL(k_evaporate, grid, dim3(256), 0, st, p.a, p.b, 0, sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
+                s->ev.push_back(p);
+                return;
+            }
+            hipEventDestroy(p.a);
+        }
+    }
+    k_evaporate<<<grid, 256, 0, st>>>(sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
 }
 
+// One generation = walk -> rank -> (evaporate) -> deposit (ACSRank_3D.hpp:252-280).  The
+// evaporation sweep of generation g only reads the field the walk is reading and writes the
+// OTHER buffer, so it is forked onto stream2 and overlaps the latency-bound walk; the deposit
+// joins both and lands on the new buffer, which then becomes current.
 int wa_acs_run(wa_acs *s, int32_t n_generations)
 {
     if (!s || n_generations < 0) return WA_ERR_ARG;
@@ -554,6 +592,12 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     const int32_t chunks = (dep_bound + 63) / 64;
     for (int32_t g = 0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
+        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ 1];
+        // fork: evaporation on stream2 once everything before this generation is done
+        HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        launch_evaporate(s, ctx->stream2, src, dst, 0, P, s->R.rho, sampled);
+        HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         EvPair *e = prof_open(s, WA_K_WALK, sampled);
         if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
@@ -568,9 +612,10 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         e = prof_open(s, WA_K_RANK, sampled);
         k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
         prof_close(s, e);
-        e = prof_open(s, WA_K_EVAPORATE, sampled);
-        launch_evaporate(s, 0, P, s->R.rho);
-        prof_close(s, e);
+        // join: the deposit needs the evaporated field
+        HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        s->cur_buf ^= 1;
+        s->D.pher = dst;
         e = prof_open(s, WA_K_DEPOSIT, sampled);
         for (int32_t c = 0; c < chunks; c++) {
             dim3 dg(8, 64, (unsigned)P);
@@ -588,6 +633,7 @@ int wa_acs_sync(wa_acs *s)
 {
     if (!s) return WA_ERR_ARG;
     wa_ctx *ctx = s->ctx;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream2));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     // fold finished event pairs into the accumulators
     for (auto &p : s->ev) {
@@ -719,10 +765,14 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats)
 {
     if (!s || slot < 0 || slot >= s->n_slots || repeats < 1) return WA_ERR_ARG;
+    // same out-of-place sweep as the generation loop; all slots flip together, so the other
+    // slots are carried across with rho = 1 (exact copy)
     for (int32_t r = 0; r < repeats; r++) {
-        EvPair *e = prof_open(s, WA_K_EVAPORATE, s->prof);
-        launch_evaporate(s, slot, 1, rho);
-        prof_close(s, e);
+        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ 1];
+        for (int32_t q = 0; q < s->n_slots; q++)
+            launch_evaporate(s, s->ctx->stream, src, dst, q, 1, q == slot ? rho : 1.0f, s->prof && q == slot);
+        s->cur_buf ^= 1;
+        s->D.pher = dst;
     }
     HIPC(s->ctx, hipGetLastError());
     return WA_OK;
