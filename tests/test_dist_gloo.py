@@ -1,0 +1,94 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Covers what bench.py
+and a multi-GPU pair batch do besides the (rank-local) HIP work: problem sharding with no overlap
+and no gap, per-rank workloads, the chunked MIN all-reduce of per-generation best costs (the only
+collective of the path), max-over-ranks timing and the whole-job rate."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from welding_robot_amd import dist as wd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from welding_robot_amd import dist as wd
+    rank, local_rank, world = wd.env_rank()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    K, chunk = 130, 50
+    rs = np.random.RandomState(100 + rank)
+    trace = np.minimum.accumulate(rs.uniform(300, 900, K)).astype(np.float32)   # a monotone best-cost history
+    glob = []
+    works = []
+    for g0 in range(0, K, chunk):                      # same chunking as bench.py
+        t = torch.from_numpy(trace[g0:g0 + chunk].copy())
+        works.append((t, wd.allreduce_min_(t, async_op=True)))
+    for t, w in works:
+        w.wait()
+        glob.append(t.numpy())
+    glob = np.concatenate(glob)
+    elapsed = 0.010 * (rank + 1)
+    out = dict(rank=rank, world=world, mine=trace.tolist(), glob=glob.tolist(),
+               tmax=wd.max_over_ranks(elapsed, dev), total=wd.sum_over_ranks(K, dev),
+               shard=wd.shard_problems(2016, rank, world), wl=wd.per_rank_workload(rank))
+    json.dump(out, open(sys.argv[1] + ".%%d" %% rank, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path / "out")], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(str(tmp_path / "out") + ".%d" % r)) for r in range(2)]
+    want = np.minimum(np.array(res[0]["mine"], np.float32), np.array(res[1]["mine"], np.float32))
+    for r in res:
+        assert np.array_equal(np.array(r["glob"], np.float32), want)  # global best per generation = MIN over ranks
+        assert r["tmax"] == 0.020 and r["total"] == 260 and r["world"] == 2
+    assert wd.aggregate_rate(res[0]["total"], res[0]["tmax"]) == 260 / 0.020
+    a, b = set(res[0]["shard"]), set(res[1]["shard"])
+    assert not (a & b) and a | b == set(range(2016)) and abs(len(a) - len(b)) <= 1
+    assert res[0]["wl"] != res[1]["wl"] and res[1]["wl"]["grid_seed"] == 2025 and res[1]["wl"]["rng_seed"] == 12346
+
+
+def test_single_process_helpers_are_identity():
+    import torch
+    t = torch.tensor([3.0, 1.0])
+    assert wd.allreduce_min_(t) is None and t.tolist() == [3.0, 1.0]
+    assert wd.max_over_ranks(1.5, torch.device("cpu")) == 1.5 and wd.sum_over_ranks(7, torch.device("cpu")) == 7
+    assert wd.shard_problems(10, 0, 1) == list(range(10)) and wd.shard_problems(10, 3, 4) == [3, 7]
+    assert wd.env_rank() == (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def test_synth_grid_matches_oracle_generator():
+    import oracle_lib as O
+    from welding_robot_amd import synth
+    for n, seed, pr in [(16, 1, 0.3), (48, 2025, 0.10)]:
+        free, cx, cy, cz, p, wall = synth.synth_grid(n, seed, pr)
+        og = O.synth_grid(n, seed, pr)
+        assert np.array_equal(free, og.free) and np.array_equal(cx, og.cx) and p == 1.0 and wall == 0
+    ids = synth.synth_weld_points(free, 48, 8)
+    assert len(set(ids.tolist())) == 8 and np.all(free[ids] == 1)

@@ -1,0 +1,349 @@
+// ACSRank_3D.hpp -- drop-in for the reference's core/ACSRank_3D.hpp on the C ABI of libweldacs.so.
+// Same class names and public members (power, _Inf_of_Points_t, ACS_Node<T>, Agent<T>, ACS_Rank with
+// searchBestPathOfPoints / getSolution / checkRoutePoints / setPoints / best_matrix / route_points)
+// so that main.cpp:280 and ACS_GTSP::read_all_segments compile unchanged; the search itself
+// (reference ACSRank_3D.hpp:134-305) runs in the HIP kernels of welding_robot_amd/csrc/.
+//
+// Extensions (non-breaking; the reference hard-wires all of these):
+//   setRngMode(WA_RNG_REF | WA_RNG_DEV)  REF = glibc rand() stream + std::sort tie order, bit-identical
+//                                        to the reference, pairs solved one after another;
+//                                        DEV (default) = counter RNG, all pairs solved concurrently
+//   setSeed(s)            REF: srand(s) instead of srand(time(0)) (:327); DEV: counter key
+//   setMaxIteration(n)    default 150 (:322)      setFixedColony(n)  0 = reference-adaptive (:247)
+//   setGraphFileCompat(b) true = reproduce the reference's damaged graph.in header (Q6); default writes
+//                         a correct file.  The cost matrix is always also kept in memory: cost_matrix().
+#ifndef _ACS_3D_HPP
+#define _ACS_3D_HPP
+#include <assert.h>
+#include <time.h>
+
+#include <algorithm>
+#include <deque>
+#include <set>
+#include <unordered_map>
+
+#include "model_grid_map.hpp"
+
+#define INF_FLOAT (1.0 / 0.0)
+#define INF_INT 0x3f3f3f3f
+#define eps 1e-8
+
+typedef Point3<int> Point3i;
+
+template <class T>
+struct _Inf_of_Points_t {
+    _Inf_of_Points_t() {}
+    _Inf_of_Points_t(T a, T b, T c) : distance(a), pheromone(b), info(c) {}
+    T distance, pheromone, info;
+};
+
+// The device keeps the lattice implicit, so adjacency_* stay empty; nodes exist only for voxels that
+// appear on a returned path (what main.cpp and read_all_segments dereference: ->pt, ->id, ->isFree).
+template <class T>
+class ACS_Node : public Vertex3<T> {
+public:
+    std::vector<ACS_Node<T> *> adjacency_nodes;
+    std::vector<_Inf_of_Points_t<T>> adjacency_infos;
+};
+
+template <class T>
+T power(T x, int y)
+{
+    T ans = 1;
+    while (y) {
+        if (y & 1) ans *= x;
+        x *= x;
+        y >>= 1;
+    }
+    return ans;
+}
+
+template <class T>
+class Agent {
+private:
+    std::vector<ACS_Node<T> *> path;
+    std::vector<int> node_index;
+
+public:
+    std::set<unsigned long int> tabu_list;
+    T L;
+    void addNextNode(ACS_Node<T> *node, int index, T _dis)
+    {
+        tabu_list.insert(node->id);
+        path.push_back(node);
+        node_index.push_back(index);
+        L += _dis;
+    }
+    void addStartNode(ACS_Node<T> *_start)
+    {
+        tabu_list.insert(_start->id);
+        path.push_back(_start);
+        L = 0;
+    }
+    void setDeadEnd() { L = INF_FLOAT; }
+    const std::vector<ACS_Node<T> *> *getPath() const { return &path; }
+    const std::vector<int> *nodeIndex() const { return &node_index; }
+    bool findPathNode(ACS_Node<T> *target)
+    {
+        for (auto node : path)
+            if (target == node) return true;
+        return false;
+    }
+    // extension: rebuild from a device result
+    void assign(const std::vector<ACS_Node<T> *> &p, const std::vector<int> &idx, T cost)
+    {
+        path = p;
+        node_index = idx;
+        tabu_list.clear();
+        for (auto n : p) tabu_list.insert(n->id);
+        L = cost;
+    }
+};
+
+class ACS_Rank : public GridMap<float> {
+public:
+    Agent<float> **best_matrix;
+    std::vector<Point3<float>> route_points;
+
+    ACS_Rank() : best_matrix(NULL) {}
+    ~ACS_Rank() { if (solver) wa_acs_destroy(solver); }
+
+    // ---- extensions
+    void setRngMode(int mode) { rng_mode = mode; }
+    void setSeed(uint64_t s) { seed = s; seeded = true; }
+    void setMaxIteration(int n) { max_iteration = n; }
+    void setFixedColony(int n) { fixed_colony = n; }
+    void setGraphFileCompat(bool b) { graph_compat = b; }
+    void setConcurrentPairs(int n) { concurrent_pairs = n; }
+    int lastStatus() const { return last_status; }
+    const std::vector<float> &cost_matrix() const { return costs; }
+
+    // reference ACSRank_3D.hpp:427-504
+    void searchBestPathOfPoints(float predict_path_len = 10, std::string read_file = "", std::string output_file = "")
+    {
+        int point_num = 0;
+        if (read_file == "") {
+            std::cout << "[ACS 3D] Please enter passing point number: ";
+            std::cin >> point_num;
+            route_points.resize(point_num);
+            std::cout << "[ACS 3D] Please enter passing point in order: " << std::endl;
+            for (int i = 0; i < point_num; i++) std::cin >> route_points[i].x >> route_points[i].y >> route_points[i].z;
+        } else {
+            FILE *fp = fopen(read_file.c_str(), "r");
+            if (fp == NULL) {
+                std::cout << "[ACS 3D] Failed to read file, reject to init." << std::endl;
+                last_status = WA_ERR_FILE;
+                return;
+            }
+            if (fscanf(fp, "%d", &point_num) != 1 || point_num < 0) point_num = 0;
+            route_points.resize(point_num);
+            for (int i = 0; i < point_num; i++)
+                if (fscanf(fp, "%f %f %f", &route_points[i].x, &route_points[i].y, &route_points[i].z) != 3) break;
+            fclose(fp);
+        }
+        // the reference only allocates best_matrix on the file branch (:456-460) and crashes on the
+        // interactive one; here both get it
+        best_matrix = new Agent<float> *[point_num];
+        for (int i = 0; i < point_num; i++) best_matrix[i] = new Agent<float>[point_num];
+        costs.assign((size_t)point_num * point_num, 0.f);
+        if (!initFromGridMap(predict_path_len)) return;
+        checkRoutePoints();
+        std::vector<int64_t> ids(point_num);
+        std::vector<float> xyz((size_t)point_num * 3);
+        for (int i = 0; i < point_num; i++) { xyz[3 * i] = route_points[i].x; xyz[3 * i + 1] = route_points[i].y; xyz[3 * i + 2] = route_points[i].z; }
+        if (point_num) wa_grid_resolve_points(device_grid(), xyz.data(), point_num, ids.data());
+        // all pairs i < j (:472-499); a pair with an unresolved point ends the loop like the reference
+        std::vector<std::pair<int, int>> pairs;
+        bool wrong = false;
+        for (int i = 0; i < point_num && !wrong; i++)
+            for (int j = i + 1; j < point_num; j++) {
+                if (ids[i] < 0 || ids[j] < 0) {
+                    printf("[ACS 3D] Wrong point : (%.3f, %.3f, %.3f) or (%.3f, %.3f, %.3f), program will exit immediately \r\n",
+                           route_points[i].x, route_points[i].y, route_points[i].z, route_points[j].x, route_points[j].y, route_points[j].z);
+                    wrong = true;
+                    last_status = WA_ERR_POINT;
+                    break;
+                }
+                pairs.push_back(std::make_pair(i, j));
+            }
+        wa_acs_params p;
+        wa_acs_default_params(&p);
+        p.max_iteration = max_iteration;
+        p.predict = predict_path_len;
+        p.fixed_colony = fixed_colony;
+        p.rng_mode = rng_mode;
+        p.seed = seed;
+        std::vector<float> order_costs;
+        const int batch = rng_mode == WA_RNG_REF ? 1 : slots;
+        for (size_t b0 = 0; b0 < pairs.size(); b0 += batch) {
+            int nb = (int)std::min<size_t>(batch, pairs.size() - b0);
+            std::vector<int64_t> s0(nb), e0(nb);
+            std::vector<uint32_t> st(nb);
+            for (int q = 0; q < nb; q++) { s0[q] = ids[pairs[b0 + q].first]; e0[q] = ids[pairs[b0 + q].second]; st[q] = (uint32_t)(b0 + q); }
+            int rc = wa_acs_solve(solver, &p, nb, s0.data(), e0.data(), st.data());  // computeSolution :480
+            if (rc == WA_OK) rc = wa_acs_reset_pheromone(solver, -1, p.pheromone_0);  // reset() :481
+            if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(weldacs_dropin::context())); last_status = rc; return; }
+            for (int q = 0; q < nb; q++) {
+                int i = pairs[b0 + q].first, j = pairs[b0 + q].second;
+                fetch_best(q);  // `best` keeps its previous path when no ant arrived (Q9)
+                best_matrix[i][j] = best;
+                best_matrix[j][i] = best;
+                costs[(size_t)i * point_num + j] = costs[(size_t)j * point_num + i] = best.L;
+                order_costs.push_back(best.L);
+                printf("[ACS 3D] <Point (%.3f, %.3f, %.3f) : Point (%.3f, %.3f, %.3f)> Path length: %.3f\r\n", route_points[i].x,
+                       route_points[i].y, route_points[i].z, route_points[j].x, route_points[j].y, route_points[j].z, best.L);
+            }
+        }
+        if (rng_mode == WA_RNG_REF) {  // hand the libc stream on to ACS_GTSP, as the process-global rand() does
+            wa_acs_rand_state(solver, weldacs_dropin::rand_state(), 0);
+            weldacs_dropin::rand_state_valid() = true;
+        }
+        if (output_file != "") write_graph(output_file, point_num, order_costs);
+        if (!wrong) last_status = WA_OK;
+        printf("[ACS 3D] %d Result has been written to \"%s\" \r\n", (int)order_costs.size(), output_file.c_str());
+    }
+
+    const Agent<float> *getSolution() const { return &best; }
+
+    void checkRoutePoints()  // :511-535 (diagnostic only)
+    {
+        int n = (int)route_points.size();
+        std::vector<float> xyz((size_t)n * 3);
+        std::vector<int64_t> ids(n);
+        for (int i = 0; i < n; i++) { xyz[3 * i] = route_points[i].x; xyz[3 * i + 1] = route_points[i].y; xyz[3 * i + 2] = route_points[i].z; }
+        if (n && device_grid()) wa_grid_resolve_points(device_grid(), xyz.data(), n, ids.data());
+        for (int i = 0; i < n; i++)
+            if (!device_grid() || ids[i] < 0)
+                printf("[ACS 3D] Invalid route point, please reset point(%.3f, %.3f, %.3f) \n", route_points[i].x, route_points[i].y, route_points[i].z);
+        printf("[ACS 3D] %d route points have been checked. \n", n);
+    }
+
+    bool setPoints(Point3<float> &start, Point3<float> &end)  // :537-565
+    {
+        if (!device_grid()) return false;
+        float xyz[6] = {start.x, start.y, start.z, end.x, end.y, end.z};
+        int64_t ids[2] = {-1, -1};
+        wa_grid_resolve_points(device_grid(), xyz, 2, ids);
+        start_id = ids[0];
+        end_id = ids[1];
+        return ids[0] >= 0 && ids[1] >= 0;
+    }
+
+    // extension: one computeSolution between the points given to setPoints (private in the reference)
+    bool solveCurrent(float predict_path_len)
+    {
+        if (start_id < 0 || end_id < 0 || !initFromGridMap(predict_path_len)) return false;
+        wa_acs_params p;
+        wa_acs_default_params(&p);
+        p.max_iteration = max_iteration; p.predict = predict_path_len; p.fixed_colony = fixed_colony;
+        p.rng_mode = rng_mode; p.seed = seed;
+        last_status = wa_acs_solve(solver, &p, 1, &start_id, &end_id, NULL);
+        if (last_status != WA_OK) return false;
+        fetch_best(0);
+        return true;
+    }
+
+    void plot_path(Agent<float> &agentK, int figureNumber)
+    {
+#ifdef WELDACS_WITH_MATPLOTLIB
+        const std::vector<ACS_Node<float> *> *path = agentK.getPath();
+        for (auto it : *path) { path_x.push_back(it->pt.x); path_y.push_back(it->pt.y); path_z.push_back(it->pt.z); }
+        std::map<std::string, std::string> keywords;
+        keywords.insert(std::pair<std::string, std::string>("c", "red"));
+        keywords.insert(std::pair<std::string, std::string>("linewidth", "2"));
+        plt::plot3(path_x, path_y, path_z, keywords, figureNumber);
+#else
+        (void)agentK; (void)figureNumber;
+#endif
+    }
+    void plot_route_point(int figureNumber)
+    {
+#ifdef WELDACS_WITH_MATPLOTLIB
+        std::map<std::string, std::string> keywords;
+        keywords.insert(std::pair<std::string, std::string>("c", "red"));
+        keywords.insert(std::pair<std::string, std::string>("marker", "o"));
+        for (auto &it : route_points) { path_x.push_back(it.x); path_y.push_back(it.y); path_z.push_back(it.z); }
+        plt::scatter(path_x, path_y, path_z, 3, keywords, figureNumber);
+#else
+        (void)figureNumber;
+#endif
+    }
+
+private:
+    wa_acs *solver = NULL;
+    int slots = 1;
+    int rng_mode = WA_RNG_DEV, max_iteration = 150, fixed_colony = 0, concurrent_pairs = 16;
+    uint64_t seed = 1;
+    bool seeded = false, graph_compat = false;
+    int last_status = WA_OK;
+    int64_t start_id = -1, end_id = -1;
+    Agent<float> best;
+    std::vector<float> costs;
+    std::vector<float> path_x, path_y, path_z;
+    std::deque<ACS_Node<float>> node_pool;
+    std::unordered_map<int32_t, ACS_Node<float> *> node_of;
+
+    // initFromGridMap :317-410 -- parameters, srand(time(0)), solver for this grid
+    bool initFromGridMap(float predict)
+    {
+        wa_ctx *ctx = weldacs_dropin::context();
+        if (!ctx || !device_grid()) { last_status = WA_ERR_STATE; return false; }
+        if (solver) { wa_acs_destroy(solver); solver = NULL; }
+        if (!seeded) seed = (uint64_t)time(0);  // :327
+        int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
+        if (colony < 1) colony = 1;
+        slots = rng_mode == WA_RNG_REF ? 1 : std::max(1, concurrent_pairs);
+        int rc = wa_acs_create(ctx, device_grid(), slots, colony, 0, &solver);
+        if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(ctx)); last_status = rc; return false; }
+        wa_acs_init_pheromone(solver, -1, 1.0f);
+        if (rng_mode == WA_RNG_REF) wa_acs_srand(solver, (uint32_t)seed);
+        printf("[ACS 3D] Created %d nodes, node cubiod [x: %d, y: %d, z: %d]\r\n", size_of_map(), rangeX, rangeY, rangeZ);
+        return true;
+    }
+    ACS_Node<float> *node(int32_t id)
+    {
+        auto it = node_of.find(id);
+        if (it != node_of.end()) return it->second;
+        node_pool.emplace_back();
+        ACS_Node<float> *n = &node_pool.back();
+        const Vertex3<float> &v = ptr_grid_map()[id / (rangeX * rangeY)][(id / rangeX) % rangeY][id % rangeX];
+        n->pt = v.pt; n->isFree = v.isFree; n->id = v.id;
+        node_of[id] = n;
+        return n;
+    }
+    void fetch_best(int slot)
+    {
+        float cost = 0;
+        int64_t len = 0;
+        wa_acs_result(solver, slot, &cost, &len, NULL, NULL, 0);
+        if (len > 0) {
+            std::vector<int32_t> ids((size_t)len);
+            std::vector<int8_t> ch((size_t)len);
+            wa_acs_result(solver, slot, &cost, &len, ids.data(), ch.data(), len);
+            std::vector<ACS_Node<float> *> p((size_t)len);
+            std::vector<int> idx((size_t)len - 1);
+            for (int64_t i = 0; i < len; i++) p[i] = node(ids[i]);
+            for (int64_t i = 0; i + 1 < len; i++) idx[i] = ch[i];
+            best.assign(p, idx, cost);
+        } else {
+            best.L = cost;  // +inf: path left as it was (Q9)
+        }
+    }
+    void write_graph(const std::string &file, int point_num, const std::vector<float> &c)
+    {
+        FILE *fp = fopen(file.c_str(), "w");
+        if (!fp) return;
+        if (graph_compat) {  // :470,:488,:500-501 byte for byte
+            fprintf(fp, "%d %d\n", 0, 0);
+            for (float v : c) fprintf(fp, "%.3f\n", v);
+            rewind(fp);
+            fprintf(fp, "%d %d\r", point_num, (int)c.size());
+        } else {
+            fprintf(fp, "%d %d\n", point_num, (int)c.size());
+            for (float v : c) fprintf(fp, "%.9g\n", (double)v);
+        }
+        fclose(fp);
+    }
+};
+
+#endif
