@@ -173,6 +173,16 @@ def main():
         evap_ms = ev["ms"] / max(ev["launches"], 1)
         alg_bytes = 48.0 * n ** 3  # 6 fp32 read + written per voxel
         achieved = alg_bytes / (evap_ms * 1e-3) / 1e9 if evap_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot host
+        # rocprofv3 itself): FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate --pmc runs
+        traffic, traffic_src = None, None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt["k_evaporate"]["grid"] == n:
+                traffic = float(pt["k_evaporate"]["fetch_bytes_corrected"] + pt["k_evaporate"]["write_bytes"])
+                traffic_src = pt["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "acs_generations_per_sec", "value": wd.aggregate_rate(total_gens, elapsed), "unit": "generations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
@@ -183,7 +193,8 @@ def main():
                        "grid": [n, n, n], "ants": args.ants, "generations": K, "problems_per_gpu": 1,
                        "global_best_allreduce": "MIN over ranks per generation, chunks of %d" % chunk if world > 1 else "n/a (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "k_evaporate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": evap_ms, "sampled_launches": ev["launches"],
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
