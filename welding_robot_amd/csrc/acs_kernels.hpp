@@ -223,11 +223,18 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     int grp = 0;             // group holding the record of `cur`
     float ublock = 0.f;      // DEV: lane i holds the uniform draw of step (step & ~63) + i
     float pp = -0.f, ph = 0.f;
+    // software pipeline: the record of `cur` (pp/ph) and the tabu probe of its neighbours (tv/hs)
+    // are issued one step early, right after `cur` became known, and consumed at the loop top
+    int32_t nb = cur + dk;
+    uint32_t hs = ((uint32_t)nb * 2654435761u) >> hshift;
+    int32_t tv = WA_HASH_EMPTY;
     if (lane_ok && j == 0) {
         const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
         pp = *reinterpret_cast<const float *>(pher_b + boff);
         ph = *reinterpret_cast<const float *>(heur_b + boff);
+        tv = tab[hs];
     }
+    int exit_code = 0;       // 1 dead end, 2 arrived, 3 limit (spill / capacity)
     for (;;) {
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
         const bool act = lane_ok && j == grp;
@@ -238,22 +245,16 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             pp = *reinterpret_cast<const float *>(pher_b + boff);
             ph = *reinterpret_cast<const float *>(heur_b + boff);
         }
-        // ---- one neighbour per active lane: sign of p = static admissibility, tabu probe in LDS
-        const int32_t nb = cur + dk;
-        uint32_t hs = ((uint32_t)nb * 2654435761u) >> hshift;
-        int32_t tv = WA_HASH_EMPTY;
-        if (act) tv = tab[hs];
-        bool unresolved = tv != nb && tv != WA_HASH_EMPTY;
-        while (__ballot(unresolved)) {  // collisions only
-            if (unresolved) {
+        // ---- tabu probe results of the active lanes; collisions (rare) walk the chain here
+        unsigned long long un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
+        while (un) {
+            if (act && tv != nb && tv != WA_HASH_EMPTY) {
                 hs = (hs + 1) & hmask;
                 tv = tab[hs];
-                unresolved = tv != nb && tv != WA_HASH_EMPTY;
             }
+            un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
         }
         const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
-        const unsigned long long m = __ballot(adm);
-        if (m == 0) { L = INFINITY; st.done = true; break; }                  // :162-166, no draw
         const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
         const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
         // total = ((((0 + a0) + a1) + ...) + a5)   (:155)   -> role 5 of the active group
@@ -271,15 +272,25 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
                 ublock = (float)wa_ctr_draw(antkey, step + (uint32_t)lane) / 2147483648.0f;
             rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), (int)(step & 63u)));
         } else {
+            // no candidate (:162-166) returns before rand() is called: only draw when one exists
+            if (__ballot(adm) == 0) { exit_code = 1; break; }
             rnd = (float)wa_glibc_next(rng_r, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
         }
         rnd *= total;                                  // :170
         const unsigned long long m2 = __ballot(adm && c >= rnd);  // :178
-        if (m2 == 0) { L = INFINITY; st.done = true; break; }     // :191-192
+        if (m2 == 0) { exit_code = 1; break; }         // no candidate (:162-166) or fall-through (:191-192)
         const int pick_lane = 63 - __clzll((long long)m2);        // first hit when scanning i = 5..0
         const int pick = pick_lane - grp * 8;
         const int32_t next = cur + __builtin_amdgcn_readlane(dk, pick);  // lane k (< 6) holds delta_k
         if (lane == pick_lane) tab[hs] = nb;           // addNextNode :75 -- the probe ended on the free slot
+        // ---- issue the next step's probe (after the insert: LDS is in order) for the new active group
+        grp = pick;
+        cur = next;
+        nb = cur + dk;
+        hs = ((uint32_t)nb * 2654435761u) >> hshift;
+        tv = WA_HASH_EMPTY;
+        if (lane_ok && j == grp) tv = tab[hs];
+        // ---- bookkeeping
         pbuf = (lane == (len & 63)) ? (next | (pick << WA_K_SHIFT)) : pbuf;  // :76-77
         if ((len & 63) == 63) {                        // block full: one coalesced store
             pflush = pbuf;
@@ -288,11 +299,11 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         len++;
         L += R.precision;                              // :78, distance == precision (:378)
         step++;
-        if (next == end) { st.done = true; break; }    // :182-186
-        cur = next;
-        grp = pick;
-        if (len >= limit) break;                       // table 3/4 full or path buffer full
+        if (next == end) { exit_code = 2; break; }     // :182-186
+        if (len >= limit) { exit_code = 3; break; }    // table 3/4 full or path buffer full
     }
+    if (exit_code == 1) L = INFINITY;
+    st.done = exit_code != 3;
     if (!st.done && len >= path_cap) {                 // the next step would not fit path[]
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
         L = INFINITY;
