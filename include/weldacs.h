@@ -144,6 +144,9 @@ int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, 
 enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_COUNT = 4 };
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
+/* diagnostic cycle counters of the walk's inner loop: all zero unless the library was built with
+ * -DWA_STAMPS (tools/walk_stamps.py); never enabled in the product build */
+int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
 /* evaporation sweep alone (ACSRank_3D.hpp:268-272) over `slot` -- for roofline measurements */
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats);
 

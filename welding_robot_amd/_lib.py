@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libweldacs.so")
+# WELDACS_LIB selects an alternative build of the same library (tuning experiments, tools/ablate.sh)
+LIB_PATH = os.environ.get("WELDACS_LIB") or os.path.join(HERE, "lib", "libweldacs.so")
 
 WA_OK = 0
 STATUS = {0: "WA_OK", 1: "WA_ERR_ARG", 2: "WA_ERR_DEVICE", 3: "WA_ERR_ALLOC", 4: "WA_ERR_FILE",
@@ -64,6 +65,7 @@ SYMBOLS = {
     "wa_acs_last_params": (C.c_int, [_V, _I, _P, _P, _P]),
     "wa_acs_profile": (C.c_int, [_V, _I, _I]),
     "wa_acs_profile_read": (C.c_int, [_V, _P, _P]),
+    "wa_acs_debug_counters": (C.c_int, [_V, _P, _I]),
     "wa_acs_evaporate": (C.c_int, [_V, _I, _F, _I]),
     "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),
 }

@@ -21,7 +21,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def hipcc():
@@ -39,18 +39,21 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in files)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: alternative output path (experiment variants built with extra -D flags)"""
+    if out is None and not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    out = out or LIB_PATH
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])
-    print(LIB_PATH)
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None,
+                extra=defs + (["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])))

@@ -32,6 +32,7 @@ struct WaAcsDev {
     uint32_t *vbits;               // [slot][max_colony][vbits_words] spill tabu bitmap (all zero at rest)
     WaSlotCtl *ctl;                // [slot]
     WaGlibcRand *rng;              // REF stream (one per solver, like the process-global rand())
+    unsigned long long *dbg;       // [16] diagnostic cycle counters (only written by -DWA_STAMPS builds)
     float *trBest, *trIter;        // [slot][trace_cap]
     int32_t *trColony, *trFinite;
     long long *trSteps;
@@ -179,6 +180,23 @@ __device__ __forceinline__ float dpp_from_above(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));
 }
 
+// In-kernel stamps (diagnostic builds only, -DWA_STAMPS): s_memtime at section boundaries of the
+// walk's inner loop, differences summed per section; ant 0 of slot 0 writes the sums to D.dbg.
+// Never enabled in the product build (cdna_hip_programming.md 7, "In-kernel stamps").
+#ifdef WA_STAMPS
+#define WA_STAMP(i)                                                                               \
+    do {                                                                                          \
+        unsigned long long t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        stamp_acc[i] += t_ - stamp_prev;                                                          \
+        stamp_prev = t_;                                                                          \
+    } while (0)
+#else
+#define WA_STAMP(i) do { } while (0)
+#endif
+
 struct WaWalkState {
     int32_t cur, len;
     uint32_t step;
@@ -198,7 +216,8 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
                                              const float *__restrict__ heur, int32_t *__restrict__ path,
                                              int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
                                              int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
-                                             int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out)
+                                             int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out,
+                                             unsigned long long *dbg)
 {
     // Lane layout: group j = lane >> 3 (j < 6), role k2 = lane & 7 (k2 < 6).  Every step, group j
     // PREFETCHES the pheromone/heuristic record of neighbour j of the current voxel (36 lanes x 2
@@ -215,45 +234,58 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     const uint32_t hmask = (1u << hash_log2) - 1u, hshift = 32 - hash_log2;
     const char *pher_b = reinterpret_cast<const char *>(pher);
     const char *heur_b = reinterpret_cast<const char *>(heur);
-    int32_t cur = st.cur, len = st.len;
-    uint32_t step = st.step;
+    // per-lane constants so that the per-step address math is one scalar multiply + one VALU add:
+    //   byte offset of (neighbour j of cur, edge k2) = cur*24 + (dj*24 + k2*4), clamped into the field
+    //   hash of (cur + dk)                           = (cur*K + dk*K) >> shift      (mod 2^32)
+    const int32_t pf_const = dj * 24 + k2 * 4;
+    const int32_t pf_lo = k2 * 4, pf_hi = last_id * 24 + k2 * 4;
+    const uint32_t hk_const = (uint32_t)dk * 2654435761u;
+    int32_t cur = st.cur, len = st.len;      // the step about to be taken is step number len - 1
     float L = st.L;
     int32_t pbuf = st.cur;   // lane (i & 63) holds path word i of the current 64-entry block
-    int32_t pflush = 0;
     int grp = 0;             // group holding the record of `cur`
-    float ublock = 0.f;      // DEV: lane i holds the uniform draw of step (step & ~63) + i
+    float ublock = 0.f;      // DEV: lane i holds the uniform draw of the step with (len & 63) == i
     float pp = -0.f, ph = 0.f;
     // software pipeline: the record of `cur` (pp/ph) and the tabu probe of its neighbours (tv/hs)
     // are issued one step early, right after `cur` became known, and consumed at the loop top
     int32_t nb = cur + dk;
-    uint32_t hs = ((uint32_t)nb * 2654435761u) >> hshift;
+    uint32_t hs = ((uint32_t)cur * 2654435761u + hk_const) >> hshift;
     int32_t tv = WA_HASH_EMPTY;
     if (lane_ok && j == 0) {
         const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
         pp = *reinterpret_cast<const float *>(pher_b + boff);
         ph = *reinterpret_cast<const float *>(heur_b + boff);
-        tv = tab[hs];
     }
+    tv = tab[hs];            // every lane probes (unmasked): only the active group's result is used
+    if (MODE == 1) ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
     int exit_code = 0;       // 1 dead end, 2 arrived, 3 limit (spill / capacity)
+#ifdef WA_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (;;) {
+        WA_STAMP(0);                             // loop back-edge + wait for the prefetched record
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
         const bool act = lane_ok && j == grp;
         if (lane_ok) {                           // prefetch the six neighbours' records (clamped: an
-            int32_t pid = cur + dj;              // out-of-bounds neighbour is never walked to)
-            pid = pid < 0 ? 0 : (pid > last_id ? last_id : pid);
-            const uint32_t boff = ((uint32_t)pid * 6u + (uint32_t)k2) * 4u;  // < 4 GiB (checked at create)
-            pp = *reinterpret_cast<const float *>(pher_b + boff);
-            ph = *reinterpret_cast<const float *>(heur_b + boff);
+            int32_t cur24 = cur * 24;            // out-of-bounds neighbour is never walked to)
+            asm volatile("" : "+s"(cur24));      // keep the multiply scalar
+            int32_t boff = cur24 + pf_const;
+            boff = boff < pf_lo ? pf_lo : (boff > pf_hi ? pf_hi : boff);   // < 2 GiB (checked at create)
+            pp = *reinterpret_cast<const float *>(pher_b + (uint32_t)boff);
+            ph = *reinterpret_cast<const float *>(heur_b + (uint32_t)boff);
         }
+        WA_STAMP(1);                             // prefetch issue
         // ---- tabu probe results of the active lanes; collisions (rare) walk the chain here
         unsigned long long un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
-        while (un) {
+        while (__builtin_expect(un != 0, 0)) {
             if (act && tv != nb && tv != WA_HASH_EMPTY) {
                 hs = (hs + 1) & hmask;
                 tv = tab[hs];
             }
             un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
         }
+        WA_STAMP(2);                             // probe wait + collision check
         const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
         const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
         const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
@@ -266,11 +298,12 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         float c = 0.f + a;
 #pragma unroll
         for (int i = 0; i < 5; i++) c = dpp_from_above(c) + a;
+        WA_STAMP(3);                                   // admissibility + both ordered scans
         float rnd;                                     // (float)rand() / (float)RAND_MAX, RAND_MAX -> 2^31 (:169)
-        if (MODE == 1) {                               // DEV draws are pure functions of (ant, step):
-            if ((step & 63u) == 0)                     // 64 of them at a time, one per lane
-                ublock = (float)wa_ctr_draw(antkey, step + (uint32_t)lane) / 2147483648.0f;
-            rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), (int)(step & 63u)));
+        if (MODE == 1) {                               // DEV draws are pure functions of (ant, step): 64 at a
+            if (__builtin_expect((len & 63) == 0, 0))  // time, one per lane, lane i = the step with len & 63 == i
+                ublock = (float)wa_ctr_draw(antkey, (uint32_t)(len + lane - 1)) / 2147483648.0f;
+            rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), len & 63));
         } else {
             // no candidate (:162-166) returns before rand() is called: only draw when one exists
             if (__ballot(adm) == 0) { exit_code = 1; break; }
@@ -278,30 +311,40 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         }
         rnd *= total;                                  // :170
         const unsigned long long m2 = __ballot(adm && c >= rnd);  // :178
-        if (m2 == 0) { exit_code = 1; break; }         // no candidate (:162-166) or fall-through (:191-192)
+        if (__builtin_expect(m2 == 0, 0)) { exit_code = 1; break; }  // no candidate (:162-166) or fall-through (:191-192)
         const int pick_lane = 63 - __clzll((long long)m2);        // first hit when scanning i = 5..0
         const int pick = pick_lane - grp * 8;
-        const int32_t next = cur + __builtin_amdgcn_readlane(dk, pick);  // lane k (< 6) holds delta_k
+        WA_STAMP(4);                                   // draw, compare, ballot, pick
         if (lane == pick_lane) tab[hs] = nb;           // addNextNode :75 -- the probe ended on the free slot
         // ---- issue the next step's probe (after the insert: LDS is in order) for the new active group
         grp = pick;
-        cur = next;
+        cur += __builtin_amdgcn_readlane(dk, pick);    // lane k (< 6) holds delta_k
         nb = cur + dk;
-        hs = ((uint32_t)nb * 2654435761u) >> hshift;
-        tv = WA_HASH_EMPTY;
-        if (lane_ok && j == grp) tv = tab[hs];
+        uint32_t curK = (uint32_t)cur * 2654435761u;
+        asm volatile("" : "+s"(curK));                 // scalar multiply; the per-lane part is hk_const
+        hs = (curK + hk_const) >> hshift;
+        tv = tab[hs];
+        WA_STAMP(5);                                   // insert + next probe issue
         // ---- bookkeeping
-        pbuf = (lane == (len & 63)) ? (next | (pick << WA_K_SHIFT)) : pbuf;  // :76-77
-        if ((len & 63) == 63) {                        // block full: one coalesced store
-            pflush = pbuf;
-            path[(len & ~63) + lane] = pflush;
+        {   // lane (len & 63) of pbuf <- path word (:76-77); one v_writelane instead of mov+cmp+cndmask.
+            // s_nop covers the "VALU-written SGPR as lane select" hazard the compiler cannot see in asm.
+            const int32_t word = cur | (pick << WA_K_SHIFT), sel = len & 63;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(pbuf) : "s"(word), "s"(sel) : "m0");
         }
+        if (__builtin_expect((len & 63) == 63, 0))     // block full: one coalesced store
+            path[(len & ~63) + lane] = pbuf;
         len++;
         L += R.precision;                              // :78, distance == precision (:378)
-        step++;
-        if (next == end) { exit_code = 2; break; }     // :182-186
-        if (len >= limit) { exit_code = 3; break; }    // table 3/4 full or path buffer full
+        WA_STAMP(6);                                   // path capture, counters
+        if (__builtin_expect(cur == end, 0)) { exit_code = 2; break; }     // :182-186
+        if (__builtin_expect(len >= limit, 0)) { exit_code = 3; break; }   // table 3/4 full or path buffer full
     }
+#ifdef WA_STAMPS
+    if (dbg && lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&dbg[i], stamp_acc[i]);
+        atomicAdd(&dbg[8], (unsigned long long)(len - 1));
+    }
+#endif
     if (exit_code == 1) L = INFINITY;
     st.done = exit_code != 3;
     if (!st.done && len >= path_cap) {                 // the next step would not fit path[]
@@ -312,7 +355,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     if (len & 63) {  // partial last block (entries [len & ~63, len))
         if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
     }
-    st.cur = cur; st.len = len; st.step = step; st.L = L;
+    st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
 }
 
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
@@ -428,7 +471,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     WaWalkState st;
     st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
     wa_walk_fast<MODE, ALPHA1>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey, rng_r, rng_f,
-                       rng_b, spill_at, st, flags_out);
+                       rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr);
     if (!st.done) wa_walk_slow<MODE>(D, R, pher, heur, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;

@@ -46,7 +46,7 @@ struct wa_acs {
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     int cur_buf;
     WaRun R;
-    bool begun;
+    bool begun, overlap_walk, overlap_rank;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
@@ -360,9 +360,9 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->cur_buf = 0;
     for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
     const int64_t n = grid->d.n;
-    if (24 * n >= (int64_t)1 << 32) {  // the walk addresses a slot's pheromone field with 32-bit byte offsets
+    if (24 * n >= (int64_t)1 << 31) {  // the walk addresses a slot's pheromone field with signed 32-bit byte offsets
         delete s;
-        return fail(ctx, WA_ERR_ARG, "wa_acs_create: grids above 178,956,970 voxels are not supported");
+        return fail(ctx, WA_ERR_ARG, "wa_acs_create: grids above 89,478,485 voxels (~447^3) are not supported");
     }
     if (path_capacity <= 0) path_capacity = n < (1 << 18) ? n : (1 << 18);
     if (path_capacity > n) path_capacity = n;
@@ -381,7 +381,9 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->hash_log2 = env_int("WA_HASH_LOG2", lg);
     if (s->hash_log2 < 6) s->hash_log2 = 6;
     if (s->hash_log2 > 14) s->hash_log2 = 14;
-    s->evap_blocks = env_int("WA_EVAP_BLOCKS", 2048);
+    s->evap_blocks = env_int("WA_EVAP_BLOCKS", 4096);
+    s->overlap_walk = env_int("WA_OVERLAP_WALK", 0) != 0;
+    s->overlap_rank = env_int("WA_OVERLAP_RANK", 0) != 0;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
@@ -399,6 +401,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     e = e ? e : dalloc(&D.vbits, S * C * D.vbits_words);
     e = e ? e : dalloc(&D.ctl, S);
     e = e ? e : dalloc(&D.rng, 1);
+    e = e ? e : dalloc(&D.dbg, 16);
     e = e ? e : dalloc(&s->d_starts, S);
     e = e ? e : dalloc(&s->d_ends, S);
     e = e ? e : dalloc(&s->d_streams, S);
@@ -415,6 +418,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     HIPC(ctx, hipMemsetAsync(D.bestmark, 0, sizeof(uint32_t) * S * n, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.vbits, 0, sizeof(uint32_t) * S * C * D.vbits_words, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.ctl, 0, sizeof(WaSlotCtl) * S, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.dbg, 0, sizeof(unsigned long long) * 16, ctx->stream));
     WaGlibcRand r0;
     wa_glibc_seed(&r0, 1);  // a process that never calls srand() behaves as srand(1)
     HIPC(ctx, hipMemcpyAsync(D.rng, &r0, sizeof r0, hipMemcpyHostToDevice, ctx->stream));
@@ -443,7 +447,7 @@ void wa_acs_destroy(wa_acs *s)
     WaAcsDev &D = s->D;
     hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
-    hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng);
+    hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
     free_trace(s);
     delete s;
@@ -577,10 +581,14 @@ static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float 
     k_evaporate<<<grid, 256, 0, st>>>(sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
 }
 
-// One generation = walk -> rank -> (evaporate) -> deposit (ACSRank_3D.hpp:252-280).  The
-// evaporation sweep of generation g only reads the field the walk is reading and writes the
-// OTHER buffer, so it is forked onto stream2 and overlaps the latency-bound walk; the deposit
-// joins both and lands on the new buffer, which then becomes current.
+// One generation = walk -> rank -> evaporate -> deposit (ACSRank_3D.hpp:252-280), enqueued on one
+// stream without host synchronisation.  The sweep is out-of-place (dst = src*rho into the other
+// pheromone buffer, which then becomes current), which makes two overlaps legal; both were
+// measured on MI355X (128^3, 256 ants) and both LOSE, so they are off by default and kept as knobs:
+//   WA_OVERLAP_WALK=1  sweep on stream2 alongside the walk (it reads the field the walk reads):
+//                      5561 vs 5764 gen/s -- its traffic lengthens the latency-bound walk by what it saves
+//   WA_OVERLAP_RANK=1  rank on stream2 alongside the sweep: 5322 gen/s -- the event fork/join
+//                      costs more than the 10 us ranking kernel it hides
 int wa_acs_run(wa_acs *s, int32_t n_generations)
 {
     if (!s || n_generations < 0) return WA_ERR_ARG;
@@ -593,11 +601,11 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     for (int32_t g = 0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
         float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ 1];
-        // fork: evaporation on stream2 once everything before this generation is done
-        HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        launch_evaporate(s, ctx->stream2, src, dst, 0, P, s->R.rho, sampled);
-        HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        if (s->overlap_walk) {  // fork the sweep before the walk
+            HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            launch_evaporate(s, ctx->stream2, src, dst, 0, P, s->R.rho, sampled);
+        }
         EvPair *e = prof_open(s, WA_K_WALK, sampled);
         if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
@@ -609,11 +617,25 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
         }
         prof_close(s, e);
-        e = prof_open(s, WA_K_RANK, sampled);
-        k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
-        prof_close(s, e);
-        // join: the deposit needs the evaporated field
-        HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (s->overlap_walk) {  // rank on the main stream, join the early sweep
+            e = prof_open(s, WA_K_RANK, sampled);
+            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
+            prof_close(s, e);
+            HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        } else if (s->overlap_rank) {  // rank on stream2 || sweep on the main stream
+            HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            k_rank<<<P, 256, 0, ctx->stream2>>>(s->D, s->R);
+            HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
+            HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        } else {  // fully serial
+            e = prof_open(s, WA_K_RANK, sampled);
+            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
+            prof_close(s, e);
+            launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
+        }
         s->cur_buf ^= 1;
         s->D.pher = dst;
         e = prof_open(s, WA_K_DEPOSIT, sampled);
@@ -761,6 +783,14 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
         if (launches) launches[i] = s->prof_n[i];
     }
     return rc;
+}
+int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset)
+{
+    if (!s || !out16) return WA_ERR_ARG;
+    HIPC(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    HIPC(s->ctx, hipMemcpy(out16, s->D.dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost));
+    if (reset) HIPC(s->ctx, hipMemset(s->D.dbg, 0, sizeof(uint64_t) * 16));
+    return WA_OK;
 }
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats)
 {
