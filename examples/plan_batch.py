@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""BASELINE config C5 in miniature or at full size: P weld points on an n^3 grid, all P(P-1)/2
+pair searches (ACS_Rank::searchBestPathOfPoints' loop, ACSRank_3D.hpp:472-499) batched across the
+slots of each GPU and sharded round-robin across ranks, then the weld-seam order by the ACS-TSP
+kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip).
+
+    python examples/plan_batch.py --grid 256 --points 64 --generations 150          # 1 GPU
+    torchrun --nproc-per-node 8 examples/plan_batch.py --grid 256 --points 64       # 8 GPUs
+
+Every pair uses its GLOBAL pair index as DEV-mode stream key, so the cost matrix -- and the tour --
+do not depend on the number of ranks or slots.  The only collective is one SUM all-reduce of the
+P x P cost matrix (each rank fills its own pairs) at the end: 16 KB at P = 64.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from welding_robot_amd import api, synth  # noqa: E402
+from welding_robot_amd import dist as wd  # noqa: E402
+
+
+def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=1, fixed_colony=0):
+    P = len(point_ids)
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    mine = wd.shard_problems(len(pairs), rank, world)
+    colony = fixed_colony or max(1, int(0.35 * predict / float(grid.precision)))
+    solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony)
+    p = api.default_params(max_iteration=generations, predict=predict, fixed_colony=fixed_colony,
+                           rng_mode=api.RNG_DEV, seed=seed)
+    cost = np.zeros((P, P), np.float64)
+    paths = {}
+    for b0 in range(0, len(mine), slots):
+        idx = mine[b0:b0 + slots]
+        solver.solve(p, [point_ids[pairs[k][0]] for k in idx], [point_ids[pairs[k][1]] for k in idx], streams=idx)
+        solver.reset_pheromone(1.0)  # reset() between problems (:481)
+        for q, k in enumerate(idx):
+            c, ids, _ = solver.result(q)
+            i, j = pairs[k]
+            cost[i, j] = cost[j, i] = c
+            paths[(i, j)] = ids
+    solver.close()
+    return cost, paths, len(mine)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=96)
+    ap.add_argument("--points", type=int, default=16)
+    ap.add_argument("--generations", type=int, default=150)
+    ap.add_argument("--slots", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=7)
+    args = ap.parse_args()
+    rank, local_rank, world = wd.env_rank()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = api.Context(local_rank)
+    n = args.grid
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    pts = synth.synth_weld_points(free, n, args.points, seed=args.seed)
+    predict = float(0.35 ** -1 * 24)  # 24 ants per search at precision 1 (ACSRank_3D.hpp:247)
+    t0 = time.perf_counter()
+    cost, paths, n_mine = plan(ctx, grid, pts, args.generations, predict, args.seed, args.slots, rank, world)
+    if world > 1:
+        t = torch.from_numpy(cost).cuda()
+        dist.all_reduce(t)  # every pair is owned by exactly one rank
+        cost = t.cpu().numpy()
+    t_pairs = time.perf_counter() - t0
+    finite = np.isfinite(cost).all()
+    out = dict(grid=n, points=args.points, pairs=args.points * (args.points - 1) // 2, world=world,
+               pairs_this_rank=n_mine, t_pairs_s=t_pairs, all_reached=bool(finite))
+    if rank == 0 and finite:
+        t1 = time.perf_counter()
+        tour = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=args.seed)
+        out.update(tour_cost=float(tour["L"][0]), tour_iterations=int(tour["iters"][0]),
+                   order=[int(e[0]) for e in tour["edges"][0]], t_gtsp_s=time.perf_counter() - t1,
+                   pair_generations_per_s=out["pairs"] * args.generations / t_pairs)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

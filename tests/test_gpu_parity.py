@@ -386,3 +386,35 @@ def test_error_codes(ctx):
     with pytest.raises(api.WeldacsError) as e:
         s3.solve(p, 4130, 17521)
     assert e.value.code == 7  # a walk outgrew path_capacity: refused rather than silently inexact
+
+
+# ------------------------------------------------------------------ C5 in miniature: batched pairs + GTSP
+def test_batched_pair_planning_matches_oracle_and_is_shard_invariant(ctx):
+    """examples/plan_batch.py: all pairs of 7 weld points on a 40^3 grid, 4 slots at a time, then the
+    seam order.  Costs equal the oracle pair by pair (stream = global pair index), a 2-way sharded
+    run gives the same matrix, and the GTSP tour equals the oracle's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plan_batch", os.path.join(os.path.dirname(G), "..", "examples", "plan_batch.py"))
+    pb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pb)
+    from welding_robot_amd import synth
+    n, P, gens, predict, seed = 40, 7, 40, 60.0, 11
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=5, occ_prob=0.12)
+    dg = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    pts = synth.synth_weld_points(free, n, P, seed=3)
+    cost, paths, _ = pb.plan(ctx, dg, pts, gens, predict, seed, slots=4)
+    og = O.Grid(cx, cy, cz, free, 1.0, 0)
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    for k, (i, j) in enumerate(pairs):
+        a = O.Acs(og)
+        a.solve(int(pts[i]), int(pts[j]), gens, predict, mode=O.DEV, seed=seed, stream=k)
+        assert bits(np.float32(cost[i, j])) == bits(a.best_L), (i, j)
+        if np.isfinite(a.best_L):
+            assert np.array_equal(paths[(i, j)], a.best_path()[0])
+    c0, _, n0 = pb.plan(ctx, dg, pts, gens, predict, seed, slots=3, rank=0, world=2)
+    c1, _, n1 = pb.plan(ctx, dg, pts, gens, predict, seed, slots=5, rank=1, world=2)
+    assert n0 + n1 == len(pairs) and np.array_equal(c0 + c1, cost)  # the SUM all-reduce of the two shards
+    assert np.isfinite(cost).all()
+    t = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=seed)
+    o = O.gtsp_solve(cost, mode=O.DEV, seed=seed)
+    assert t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
