@@ -99,14 +99,14 @@ __global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta)
 }
 
 // :247-249 -- colony in double then truncated, lambda double -> float, Q float
-__device__ __forceinline__ void wa_next_params(WaSlotCtl &c, const WaRun &R)
+__device__ __forceinline__ void wa_next_params(WaSlotCtl &c, const WaRun &R, int which)
 {
     int32_t colony;
     if (R.fixed_colony > 0) colony = R.fixed_colony;
     else colony = (int32_t)(0.35 * (double)(c.bestL < R.predict ? c.bestL : R.predict) / (double)R.precision);
-    c.colony = colony;
-    c.lambda = (float)(0.2 * (double)colony);
-    c.Q = R.pheromone_0 / c.lambda * (c.bestL == INFINITY ? R.predict : c.bestL);
+    c.colony[which] = colony;
+    c.lambda[which] = (float)(0.2 * (double)colony);
+    c.Q[which] = R.pheromone_0 / c.lambda[which] * (c.bestL == INFINITY ? R.predict : c.bestL);
 }
 
 __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long *starts,
@@ -123,7 +123,7 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.best_len = 0;
     c.n_dep = 0;
     c.flags = 0;
-    wa_next_params(c, R);
+    wa_next_params(c, R, 0);
     D.ctl[slot] = c;
 }
 
@@ -481,26 +481,26 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
 template <bool ALPHA1>
-__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2)
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
-    if (ant >= c->colony) return;
-    if (c->colony > D.max_colony) return;  // flagged by k_rank
-    const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)c->gen), (uint32_t)ant);
+    const int32_t colony = c->colony[gen & 1];
+    if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
+    const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0;
     wa_walk_one<1, ALPHA1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
 // from the shared glibc stream in exactly the reference's order (:252-261)
-__global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2)
+__global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y;
     const WaSlotCtl *c = &D.ctl[slot];
-    int32_t colony = c->colony;
+    int32_t colony = c->colony[gen & 1];
     if (colony > D.max_colony) return;
     // every lane keeps a private copy of the 31-word state: all lanes draw in lockstep, so the
     // copies stay identical and no cross-lane traffic is needed
@@ -639,12 +639,11 @@ __device__ inline void wa_std_sort(WaRec *v, int32_t n)
 // The (L, ant) sort keys are staged in LDS (up to WA_RANK_LDS ants) so the counting rank reads
 // broadcast LDS words instead of a dependent chain of global loads.
 #define WA_RANK_LDS 2048
-__global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
+__global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 {
     const int32_t slot = blockIdx.x, tid = threadIdx.x;
     WaSlotCtl *ctl = &D.ctl[slot];
-    const int32_t colony = ctl->colony;
-    const int32_t gen = ctl->gen;
+    const int32_t colony = ctl->colony[gen & 1];
     const float *antL = D.antL + (int64_t)slot * D.max_colony;
     const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
     int32_t *perm = D.perm + (int64_t)slot * D.max_colony;
@@ -689,7 +688,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
     if (colony > 0) { iterL = __uint_as_float((uint32_t)(s_min >> 32)); iterAnt = (int32_t)(s_min & 0xffffffffu); }
     float bestL = ctl->bestL;
     uint32_t ver = ctl->best_ver;
-    const float lambda = ctl->lambda, Q = ctl->Q;
+    const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
     __syncthreads();
     if (iterAnt >= 0 && iterL < bestL) {  // best = agentK (:264): copy the path, re-stamp membership
         const int32_t blen = antLen[iterAnt];
@@ -760,8 +759,152 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R)
         c.dep_bestL = bestL;
         c.n_dep = s_ndep;
         c.gen = gen + 1;
-        wa_next_params(c, R);
+        wa_next_params(c, R, (gen + 1) & 1);
         *ctl = c;
+    }
+}
+
+// ------------------------------------------------------------------ fused post-walk launch (DEV mode)
+// One launch = ranking and deposit marking (blocks [0, 512)) + the evaporation sweep (blocks [512, 512+E)):
+// the sweep only touches the pheromone buffers, rank/mark only the ants' results and the rank
+// masks, so they share a launch instead of three dependent kernel boundaries.  Every mark block
+// re-derives the (L, ant) ranking in LDS (256 broadcast reads per thread); block 0 additionally
+// PUBLISHES what k_rank publishes (global best, perm/depA for the apply pass, trace, the next
+// generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
+// Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
+__global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *__restrict__ src_base,
+                                                        float *__restrict__ dst_base, int32_t E, int32_t gen)
+{
+    const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
+    // their latency-bound work hides under the sweep blocks that follow
+    if ((int32_t)blockIdx.x >= 512) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
+        const int32_t ebx = (int32_t)blockIdx.x - 512;
+        const float rho = R.rho;
+        const int64_t n_floats = 6 * D.d.n;
+        const float *src = src_base + (int64_t)slot * D.pher_stride;
+        float *dst = dst_base + (int64_t)slot * D.pher_stride;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const int64_t n4 = n_floats >> 2;
+        const int64_t gsz = (int64_t)E * blockDim.x;
+        int64_t i = (int64_t)ebx * blockDim.x + tid;
+        for (; i + 3 * gsz < n4; i += 4 * gsz) {
+            float4 a = s4[i], b = s4[i + gsz], c = s4[i + 2 * gsz], d = s4[i + 3 * gsz];
+            a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
+            b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
+            c.x *= rho; c.y *= rho; c.z *= rho; c.w *= rho;
+            d.x *= rho; d.y *= rho; d.z *= rho; d.w *= rho;
+            d4[i] = a; d4[i + gsz] = b; d4[i + 2 * gsz] = c; d4[i + 3 * gsz] = d;
+        }
+        for (; i < n4; i += gsz) {
+            float4 a = s4[i];
+            a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
+            d4[i] = a;
+        }
+        int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + tid;
+        if (t < n_floats) dst[t] = src[t] * rho;
+        return;
+    }
+    // ---- rank + mark
+    const int32_t mb = (int32_t)blockIdx.x;  // 0..511: (bx = mb & 7, rank bit = mb >> 3)
+    WaSlotCtl *ctl = &D.ctl[slot];
+    const int32_t colony = ctl->colony[gen & 1];
+    const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
+    const float *antL = D.antL + (int64_t)slot * D.max_colony;
+    const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
+    __shared__ unsigned long long s_keys[WA_RANK_LDS];
+    __shared__ int32_t s_perm[WA_RANK_LDS];
+    __shared__ int32_t s_ndep, s_fin;
+    __shared__ unsigned long long s_steps;
+    if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
+    if (colony > D.max_colony || colony > WA_RANK_LDS) {
+        if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
+        return;
+    }
+    int32_t myfin = 0;
+    unsigned long long mysteps = 0;
+    for (int32_t a = tid; a < colony; a += blockDim.x) {
+        const float La = antL[a];
+        s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
+        if (mb == 0) { myfin += (La != INFINITY) ? 1 : 0; mysteps += (unsigned long long)(antLen[a] - 1); }
+    }
+    __syncthreads();
+    for (int32_t a = tid; a < colony; a += blockDim.x) {  // ascending (L, ant) by counting (:273-275, DEV tie rule)
+        const unsigned long long ka = s_keys[a];
+        int32_t r = 0;
+#pragma unroll 8
+        for (int32_t b = 0; b < colony; b++) r += s_keys[b] < ka ? 1 : 0;
+        s_perm[r] = a;
+        const int32_t o = r + 1;
+        const float La = __uint_as_float((uint32_t)(ka >> 32));
+        const bool ok = !(La == INFINITY || (float)o > lambda - 1);  // :200
+        if (ok) atomicMax(&s_ndep, o);
+        if (mb == 0) {  // publish for the apply pass
+            D.perm[(int64_t)slot * D.max_colony + r] = a;
+            D.depA[(int64_t)slot * D.max_colony + r] = ok ? (lambda - (float)o) * Q / La : 0.f;  // :211
+        }
+    }
+    if (mb == 0) {
+        for (int o = 32; o > 0; o >>= 1) { myfin += __shfl_down(myfin, o, 64); mysteps += __shfl_down(mysteps, o, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&s_fin, myfin); atomicAdd(&s_steps, mysteps); }
+    }
+    __syncthreads();
+    const int32_t n_dep = s_ndep;
+    if (mb == 0) {  // ---- publish: iteration best -> global best (:263-264), trace, next parameters (:247-249)
+        float iterL = INFINITY;
+        int32_t iterAnt = -1;
+        if (colony > 0) { iterAnt = s_perm[0]; iterL = antL[iterAnt]; }  // rank 1 = first ant with the minimal L
+        float bestL = ctl->bestL;
+        uint32_t ver = ctl->best_ver;
+        int32_t blen = ctl->best_len;
+        if (iterAnt >= 0 && iterL < bestL) {
+            blen = antLen[iterAnt];
+            const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
+            int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
+            uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+            ver = ver + 1;
+            for (int32_t i = tid; i < blen; i += blockDim.x) {
+                int32_t w = srcp[i];
+                dstp[i] = w;
+                mark[w & WA_ID_MASK] = ver;
+            }
+            bestL = iterL;
+        }
+        if (tid == 0) {
+            if (gen < D.trace_cap) {
+                int64_t t = (int64_t)slot * D.trace_cap + gen;
+                D.trBest[t] = bestL;
+                D.trIter[t] = iterL;
+                D.trColony[t] = colony;
+                D.trFinite[t] = s_fin;
+                D.trSteps[t] = (long long)s_steps;
+            }
+            WaSlotCtl c = *ctl;
+            c.bestL = bestL;
+            c.best_len = blen;
+            c.best_ver = ver;
+            c.dep_lambda = lambda;
+            c.dep_Q = Q;
+            c.dep_bestL = bestL;
+            c.n_dep = n_dep;
+            c.gen = gen + 1;
+            wa_next_params(c, R, (gen + 1) & 1);
+            *ctl = c;  // nothing a sibling block reads during this launch changes: [gen&1] slots, start/end/stream
+        }
+    }
+    // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
+    const int32_t bit = mb >> 3, bx = mb & 7, o = bit + 1;
+    if (o > n_dep) return;
+    const int32_t a = s_perm[o - 1];
+    const int32_t len = antLen[a];
+    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
+    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += 8 * blockDim.x) {
+        int32_t w = path[i];
+        int32_t v = path[i - 1] & WA_ID_MASK;
+        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        atomicOr(&mask[e], 1ULL << bit);
     }
 }
 

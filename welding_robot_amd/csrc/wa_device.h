@@ -38,9 +38,11 @@ struct WaRun {
 struct WaSlotCtl {
     int32_t start, end;
     uint32_t stream;
-    int32_t gen;            // generation about to be walked
-    int32_t colony;         // ants of that generation           (:247)
-    float lambda, Q;        // of that generation                (:248-249)
+    int32_t gen;            // generations completed (informational: kernels get `gen` as an argument)
+    // parameters of generation g live in slot [g & 1]: the block that publishes generation g+1's
+    // values writes the other slot while its sibling blocks still read generation g's
+    int32_t colony[2];      // ants                               (:247)
+    float lambda[2], Q[2];  //                                    (:248-249)
     float bestL;            // best.L                            (:232,:263)
     int32_t best_len;
     uint32_t best_ver;      // bestmark[v] == best_ver <=> v on best path
@@ -48,7 +50,6 @@ struct WaSlotCtl {
     float dep_lambda, dep_Q, dep_bestL;
     int32_t n_dep;          // ranks 1..n_dep deposit             (:200)
     int32_t flags;
-    int32_t pad;
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index

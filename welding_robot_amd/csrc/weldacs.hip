@@ -46,7 +46,7 @@ struct wa_acs {
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     int cur_buf;
     WaRun R;
-    bool begun, overlap_walk, overlap_rank;
+    bool begun, overlap_walk, overlap_rank, fuse;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
@@ -384,6 +384,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->evap_blocks = env_int("WA_EVAP_BLOCKS", 4096);
     s->overlap_walk = env_int("WA_OVERLAP_WALK", 0) != 0;
     s->overlap_rank = env_int("WA_OVERLAP_RANK", 0) != 0;
+    s->fuse = env_int("WA_FUSE", 1) != 0;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
@@ -581,6 +582,26 @@ static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float 
     k_evaporate<<<grid, 256, 0, st>>>(sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
 }
 
+// the fused post-walk launch (sweep + rank + mark), timed per dispatch when sampled
+static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int32_t gen, bool timed)
+{
+    dim3 grid((unsigned)(s->evap_blocks + 512), (unsigned)P);
+    if (timed) {
+        EvPair p;
+        p.cls = WA_K_EVAPORATE;
+        if (hipEventCreate(&p.a) == hipSuccess) {
+            if (hipEventCreate(&p.b) == hipSuccess) {
+                hipExtLaunchKernelGGL(k_evap_rank_mark, grid, dim3(256), 0, s->ctx->stream, p.a, p.b, 0, s->D, s->R, src, dst,
+                                      s->evap_blocks, gen);
+                s->ev.push_back(p);
+                return;
+            }
+            hipEventDestroy(p.a);
+        }
+    }
+    k_evap_rank_mark<<<grid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, s->evap_blocks, gen);
+}
+
 // One generation = walk -> rank -> evaporate -> deposit (ACSRank_3D.hpp:252-280), enqueued on one
 // stream without host synchronisation.  The sweep is out-of-place (dst = src*rho into the other
 // pheromone buffer, which then becomes current), which makes two overlaps legal; both were
@@ -598,8 +619,11 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     const size_t shmem = sizeof(int32_t) << s->hash_log2;
     const int32_t dep_bound = (int32_t)(0.2 * s->colony_bound) + 1;
     const int32_t chunks = (dep_bound + 63) / 64;
+    const bool fused = s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
+                       !s->overlap_walk && !s->overlap_rank;
     for (int32_t g = 0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
+        const int32_t gen = s->gens_enqueued;  // == the device-side generation counter since wa_acs_begin
         float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ 1];
         if (s->overlap_walk) {  // fork the sweep before the walk
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -610,29 +634,39 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
                 dim3 wg((unsigned)s->colony_bound, (unsigned)P);
-                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
-                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
+                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
             }
         } else {
-            k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2);
+            k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
         }
         prof_close(s, e);
+        if (fused) {  // DEV fast path: walk -> {sweep + rank + mark} -> apply
+            launch_fused(s, src, dst, P, gen, sampled);
+            s->cur_buf ^= 1;
+            s->D.pher = dst;
+            e = prof_open(s, WA_K_DEPOSIT, sampled);
+            k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
+            prof_close(s, e);
+            s->gens_enqueued++;
+            continue;
+        }
         if (s->overlap_walk) {  // rank on the main stream, join the early sweep
             e = prof_open(s, WA_K_RANK, sampled);
-            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
+            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
             prof_close(s, e);
             HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         } else if (s->overlap_rank) {  // rank on stream2 || sweep on the main stream
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            k_rank<<<P, 256, 0, ctx->stream2>>>(s->D, s->R);
+            k_rank<<<P, 256, 0, ctx->stream2>>>(s->D, s->R, gen);
             HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
             HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         } else {  // fully serial
             e = prof_open(s, WA_K_RANK, sampled);
-            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R);
+            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
             prof_close(s, e);
             launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
         }
