@@ -258,7 +258,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     }
     tv = tab[hs];            // every lane probes (unmasked): only the active group's result is used
     if (MODE == 1) ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
-    int exit_code = 0;       // 1 dead end, 2 arrived, 3 limit (spill / capacity)
+    bool dead = false;
 #ifdef WA_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -306,12 +306,12 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), len & 63));
         } else {
             // no candidate (:162-166) returns before rand() is called: only draw when one exists
-            if (__ballot(adm) == 0) { exit_code = 1; break; }
+            if (__ballot(adm) == 0) { dead = true; break; }
             rnd = (float)wa_glibc_next(rng_r, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
         }
         rnd *= total;                                  // :170
         const unsigned long long m2 = __ballot(adm && c >= rnd);  // :178
-        if (__builtin_expect(m2 == 0, 0)) { exit_code = 1; break; }  // no candidate (:162-166) or fall-through (:191-192)
+        if (__builtin_expect(m2 == 0, 0)) { dead = true; break; }  // no candidate (:162-166) or fall-through (:191-192)
         const int pick_lane = 63 - __clzll((long long)m2);        // first hit when scanning i = 5..0
         const int pick = pick_lane - grp * 8;
         WA_STAMP(4);                                   // draw, compare, ballot, pick
@@ -336,9 +336,10 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         len++;
         L += R.precision;                              // :78, distance == precision (:378)
         WA_STAMP(6);                                   // path capture, counters
-        if (__builtin_expect(cur == end, 0)) { exit_code = 2; break; }     // :182-186
-        if (__builtin_expect(len >= limit, 0)) { exit_code = 3; break; }   // table 3/4 full or path buffer full
+        // arrived (:182-186), or the table is 3/4 full / the path buffer is full: one test, sorted out below
+        if (__builtin_expect((cur == end) | (len >= limit), 0)) break;
     }
+    const int exit_code = dead ? 1 : (cur == end ? 2 : 3);  // 1 dead end, 2 arrived, 3 limit (spill / capacity)
 #ifdef WA_STAMPS
     if (dbg && lane == 0) {
         for (int i = 0; i < 8; i++) atomicAdd(&dbg[i], stamp_acc[i]);
