@@ -200,7 +200,8 @@ def main():
                                    "one independent problem per GPU (C4)" % (n, args.ants, K),
                        "grid": [n, n, n], "ants": args.ants, "generations": K, "problems_per_gpu": 1,
                        "global_best_allreduce": "RCCL MIN over ranks per generation, chunks of %d, async" % chunk if dist_on else "n/a (1 GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "k_evaporate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_evap_rank_mark (evaporation sweep; the rank/mark blocks of the same launch hide under it)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": evap_ms, "sampled_launches": ev["launches"],

@@ -238,7 +238,8 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     //   byte offset of (neighbour j of cur, edge k2) = cur*24 + (dj*24 + k2*4), clamped into the field
     //   hash of (cur + dk)                           = (cur*K + dk*K) >> shift      (mod 2^32)
     const int32_t pf_const = dj * 24 + k2 * 4;
-    const int32_t pf_lo = k2 * 4, pf_hi = last_id * 24 + k2 * 4;
+    const int32_t kc = k2 < 6 ? k2 : 5;       // idle lanes (roles 6,7 / groups 6,7) load too, harmlessly in range
+    const int32_t pf_lo = kc * 4, pf_hi = last_id * 24 + kc * 4;
     const uint32_t hk_const = (uint32_t)dk * 2654435761u;
     int32_t cur = st.cur, len = st.len;      // the step about to be taken is step number len - 1
     float L = st.L;
@@ -267,9 +268,9 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         WA_STAMP(0);                             // loop back-edge + wait for the prefetched record
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
         const bool act = lane_ok && j == grp;
-        if (lane_ok) {                           // prefetch the six neighbours' records (clamped: an
-            int32_t cur24 = cur * 24;            // out-of-bounds neighbour is never walked to)
-            asm volatile("" : "+s"(cur24));      // keep the multiply scalar
+        {                                        // prefetch the six neighbours' records; every lane loads
+            int32_t cur24 = cur * 24;            // (no exec masking): addresses are clamped into the field,
+            asm volatile("" : "+s"(cur24));      // an out-of-bounds neighbour is never walked to
             int32_t boff = cur24 + pf_const;
             boff = boff < pf_lo ? pf_lo : (boff > pf_hi ? pf_hi : boff);   // < 2 GiB (checked at create)
             pp = *reinterpret_cast<const float *>(pher_b + (uint32_t)boff);
