@@ -1,0 +1,142 @@
+"""Edge cases of the ACS path on the GPU against the C oracle (DEV mode, bit-exact): degenerate
+inputs, parameter ranges the fast paths do not cover, and the slower generic kernels."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from welding_robot_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def box_grid(nx, ny, nz, occ_prob=0.0, seed=1, p=1.0):
+    rs = np.random.RandomState(seed)
+    free = (rs.uniform(size=nx * ny * nz) >= occ_prob).astype(np.uint8)
+    return O.Grid(np.arange(nx, dtype=np.float32) * p, np.arange(ny, dtype=np.float32) * p, np.arange(nz, dtype=np.float32) * p,
+                  free, p, 0)
+
+
+def run_both(ctx, og, sid, eid, iters, predict, fixed=0, seed=3, stream=0, max_colony=None, path_capacity=0, **par):
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+    s = api.AcsSolver(ctx, dg, 1, max_colony or max(bound, 1), path_capacity)
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_DEV, seed=seed, **par)
+    s.init_pheromone(par.get("pheromone_0", 1.0))
+    s.solve(p, sid, eid, streams=[stream])
+    a = O.Acs(og, pheromone_0=par.get("pheromone_0", 1.0))
+    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream,
+                 alpha=par.get("alpha", 1), beta=par.get("beta", 0.6), rho=par.get("rho", 0.8), pheromone_0=par.get("pheromone_0", 1.0))
+    t = s.trace()
+    if iters:
+        assert np.array_equal(t["steps"], tr["steps"])
+        assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(t["finite"], tr["finite"])
+        assert np.array_equal(t["colony"], tr["colony"])
+    cost, path, ch = s.result()
+    assert bits(cost) == bits(a.best_L)
+    if np.isfinite(cost):
+        assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
+    assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+    return s, a, t
+
+
+def test_start_equals_end_never_arrives(ctx):
+    og = box_grid(8, 8, 8)
+    s, a, t = run_both(ctx, og, 100, 100, 5, 20.0, fixed=8)
+    assert np.isinf(a.best_L) and np.all(t["finite"] == 0)
+    assert s.result()[1].size == 0  # cost +inf is a valid result with an empty path
+
+
+def test_walled_in_start_dies_immediately(ctx):
+    og = box_grid(6, 6, 6)
+    f = og.free.reshape(6, 6, 6)
+    f[2, 2, 3] = f[2, 2, 1] = f[2, 3, 2] = f[2, 1, 2] = f[3, 2, 2] = f[1, 2, 2] = 0  # all six neighbours of (2,2,2)
+    sid = (2 * 6 + 2) * 6 + 2
+    s, a, t = run_both(ctx, og, sid, 215, 4, 20.0, fixed=6)
+    assert np.all(t["steps"] == 0) and np.isinf(a.best_L)
+
+
+@pytest.mark.parametrize("dims", [(1, 9, 9), (9, 1, 9), (9, 9, 1), (1, 1, 12), (2, 2, 2)])
+def test_thin_grids(ctx, dims):
+    nx, ny, nz = dims
+    og = box_grid(nx, ny, nz, occ_prob=0.1 if nx * ny * nz > 20 else 0.0, seed=nx + 2 * ny)
+    og.free[0] = og.free[-1] = 1
+    run_both(ctx, og, 0, nx * ny * nz - 1, 12, 30.0, fixed=10, seed=9)
+
+
+def test_zero_colony_and_zero_iterations(ctx):
+    og = box_grid(6, 6, 6)
+    run_both(ctx, og, 0, 215, 3, 1.0)            # colony = (int)(0.35*1/1) = 0 ants: nothing ever moves
+    run_both(ctx, og, 0, 215, 0, 30.0, fixed=4)  # no generation at all
+
+
+@pytest.mark.parametrize("par", [dict(alpha=2), dict(alpha=3, beta=0.3), dict(alpha=0), dict(rho=0.5, beta=0.9),
+                                 dict(pheromone_0=0.25)])
+def test_parameter_ranges(ctx, par):
+    og = box_grid(14, 12, 10, occ_prob=0.15, seed=4)
+    og.free[0] = og.free[-1] = 1
+    run_both(ctx, og, 0, og.n - 1, 25, 40.0, fixed=24, seed=21, **par)
+
+
+def test_non_unit_precision_and_anisotropic_coords(ctx):
+    og = box_grid(10, 11, 12, occ_prob=0.1, seed=6, p=0.0173)
+    og.free[0] = og.free[-1] = 1
+    run_both(ctx, og, 0, og.n - 1, 30, 0.9, seed=5)  # adaptive colony (Q1) at p = 0.0173
+
+
+def test_more_than_64_depositing_ranks_uses_chunked_deposit(ctx):
+    """lambda - 1 > 64 needs colony >= 326: the deposit runs in 64-rank chunks and the unfused sequence."""
+    og = box_grid(12, 12, 12, occ_prob=0.1, seed=8)
+    og.free[0] = og.free[-1] = 1
+    s, a, t = run_both(ctx, og, 0, og.n - 1, 8, 10.0, fixed=400, seed=2)
+    assert t["finite"].max() > 64
+
+
+def test_colony_above_lds_rank_limit(ctx):
+    """> 2048 ants: ranking reads its keys from global memory (k_rank's generic branch)."""
+    og = box_grid(10, 10, 10, occ_prob=0.1, seed=9)
+    og.free[0] = og.free[-1] = 1
+    run_both(ctx, og, 0, og.n - 1, 3, 10.0, fixed=2100, seed=4)
+
+
+def test_exact_path_capacity_and_reuse_of_a_solver(ctx):
+    og = box_grid(5, 1, 1)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, 1.0, 0)
+    s = api.AcsSolver(ctx, dg, 1, 4, path_capacity=5)  # the only path 0-1-2-3-4 has exactly 5 nodes
+    p = api.default_params(max_iteration=3, predict=10.0, fixed_colony=4, rng_mode=api.RNG_DEV, seed=1)
+    s.solve(p, 0, 4)
+    cost, path, _ = s.result()
+    assert cost == 4.0 and path.tolist() == [0, 1, 2, 3, 4]
+    # same solver, new problem after reset(): equals a fresh oracle whose field was reset() the same way
+    s.reset_pheromone(1.0)
+    s.solve(p, 4, 0)
+    a = O.Acs(og)
+    a.reset(1.0)
+    a.solve(4, 0, 3, 10.0, fixed_colony=4, mode=O.DEV, seed=1, stream=0)
+    assert s.result()[1].tolist() == [4, 3, 2, 1, 0] and np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+
+
+def test_stepwise_run_equals_single_solve(ctx):
+    og = box_grid(12, 12, 12, occ_prob=0.12, seed=3)
+    og.free[0] = og.free[-1] = 1
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, 1.0, 0)
+    p = api.default_params(max_iteration=30, predict=60.0, fixed_colony=20, rng_mode=api.RNG_DEV, seed=5)
+    a = api.AcsSolver(ctx, dg, 1, 20)
+    a.solve(p, 0, og.n - 1)
+    b = api.AcsSolver(ctx, dg, 1, 20)
+    b.begin(p, 0, og.n - 1)
+    for chunk in (1, 7, 2, 20):  # odd chunk sizes: the parameter ping-pong must follow the generation parity
+        b.run(chunk)
+    b.sync()
+    assert np.array_equal(bits(a.pheromone()), bits(b.pheromone())) and np.array_equal(a.result()[1], b.result()[1])
+    assert np.array_equal(bits(a.trace()["bestL"]), bits(b.trace()["bestL"]))
