@@ -156,3 +156,198 @@ __global__ __launch_bounds__(256) void k_gtsp(WaGtspDev G)
         }
     }
 }
+
+// ------------------------------------------------------------------ fast path, n <= 256 cities
+// lanes = ants (ant k = thread k; ceil(n/64) wavefronts per instance).  What makes it fast:
+//   * `info` (pheromone^1 * heuristic^6, rebuilt every iteration :114-119) lives in LDS with an ODD
+//     row stride (n | 1 doubles), so 64 ants standing on 64 different cities read 64 different
+//     banks; pheromone / heuristic stay in global memory (L2-resident, touched n^2 per iteration);
+//   * the unvisited set J[k] (a std::set in the reference, :98) is a register bitmask;
+//   * the two ordered passes of select_next (:127-142) are plain predicated loops over the
+//     cities: adding +0.0 for a visited city leaves the fp64 partial sums bit-identical;
+//   * the tour length is accumulated while the tour is built -- same additions, same order as
+//     ACS_Tour::calc (:36-44), closing edge excluded.
+// NW = number of 64-bit words of the unvisited mask (n <= 64*NW).  INFO_LDS: info fits in LDS.
+// 1.0 or 0.0 from bit c of a 32-bit mask word, built with two integer ops (no compare / select):
+// the visited mask then enters the ordered sum as fma(x, m, sum) -- exact, because x * 1.0 and
+// x * 0.0 are exact for finite x, so the fma rounds once exactly like `sum + x` / leaves sum alone.
+__device__ __forceinline__ double wa_bit_as_double(uint32_t word, int c)
+{
+    const uint32_t hi = ((word >> c) & 1u) * 0x3FF00000u;
+    return __hiloint2double((int)hi, 0);
+}
+template <int NW, bool INFO_LDS, bool PREFIX>
+__global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
+{
+    extern __shared__ double lds_info[];
+    const int32_t inst = blockIdx.x, tid = threadIdx.x, n = G.n;
+    // rows are padded to the full mask width (+1: odd stride) so the city loops have a fixed trip
+    // count of 64 per mask word and unroll into batches of independent LDS reads feeding the
+    // (inherently serial) fp64 add chain; columns >= n are never selected (their mask bits are 0)
+    const int32_t ld = 64 * NW + 1;
+    const int64_t nn = (int64_t)n * n;
+    const double *dist = G.dist + inst * nn;
+    double *pher = G.pher + inst * nn, *h6 = G.h6 + inst * nn;
+    double *info = INFO_LDS ? lds_info : G.info + inst * (int64_t)ld * n;
+    double *prefix = lds_info + (int64_t)ld * n + (int64_t)tid * ld;  // PREFIX: this ant's running sums (odd stride)
+    int32_t *tours = G.tours + inst * nn * 2;  // [ant][step] -> next city (n*n ints used)
+    int32_t *best = G.best + (int64_t)inst * n * 2;
+    const double INF = (double)0x3f3f3f3f;  // ACS_GTSP.hpp:19
+    const double alpha = 0.1;               // :189
+    __shared__ double s_L[256];
+    __shared__ double s_pher0, s_bestL, s_last, s_nowL;
+    __shared__ int32_t s_bad, s_nowk, s_stop, s_it;
+    if (tid == 0) {
+        double tmp = 0;
+        for (int32_t i = 0; i < n; i++)
+            for (int32_t j = i + 1; j < n; j++) tmp += dist[(int64_t)i * n + j];  // :239-249
+        s_pher0 = (double)G.cnt / (tmp * n);
+        s_bestL = INF; s_last = INF; s_bad = 0; s_stop = 0; s_it = 0;
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < nn; e += blockDim.x) {
+        int32_t i = (int32_t)(e / n), j = (int32_t)(e % n);
+        pher[e] = s_pher0;
+        double h = 1 / ((i == j ? 0.0 : dist[e]) + 1e-8);  // :211
+        h6[e] = wa_powi(h, 6);                               // :118
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < (int64_t)ld * n; e += blockDim.x) info[e] = 0.0;  // padding columns stay 0
+    __syncthreads();
+    const int32_t max_it = G.max_iterations > 0 ? G.max_iterations : n * n;  // :216
+    int32_t rf = 0, rb = 0;
+    int32_t rr[31];
+    if (G.rng_mode == 0 && tid == 0) {
+        for (int i = 0; i < 31; i++) rr[i] = G.rng->r[i];
+        rf = G.rng->f;
+        rb = G.rng->b;
+    }
+    const int32_t ncol = (n + 15) & ~15;  // city loops run over whole 16-column batches (padding is masked out)
+    const int32_t k = tid;  // lanes = ants.  (Fewer ants per wavefront does not help: every ant's n x n
+                            // ordered fp64 work is serial inside its lane whatever the other lanes do.)
+    for (int32_t it = 0; it < max_it; it++) {
+        if (tid == 0) s_stop = s_bad > n ? 1 : 0;  // :263
+        __syncthreads();
+        if (s_stop) break;
+        for (int64_t e = tid; e < nn; e += blockDim.x) {  // reset :114-119
+            int32_t i = (int32_t)(e / n), j = (int32_t)(e % n);
+            info[(int64_t)i * ld + j] = wa_powi(pher[e], 1) * h6[e];
+        }
+        if (G.rng_mode == 0 && tid == 0)  // the libc draws of this iteration in (step, ant) order
+            for (int32_t q = 0; q < n * (n - 1); q++) G.rbuf[q] = wa_glibc_next(rr, rf, rb);
+        __syncthreads();
+        if (k < n) {  // construct_solution :146-159 for ant k
+            const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(G.seed, G.stream0 + (uint32_t)inst, (uint32_t)it), (uint32_t)k);
+            unsigned long long J[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int32_t cnt = n - w * 64;
+                J[w] = cnt >= 64 ? ~0ULL : (cnt > 0 ? ((1ULL << cnt) - 1ULL) : 0ULL);
+            }
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+                if ((k >> 6) == w) J[w] &= ~(1ULL << (k & 63));  // J[i].erase(r1[i]) :111
+            int32_t r = k, left = n - 1;
+            double L = 0;
+            for (int32_t step = 0; step < n; step++) {
+                int32_t next = k;  // r1[k]
+                if (left > 0) {    // select_next :122-144
+                    const int32_t rv = G.rng_mode == 0 ? G.rbuf[step * n + k] : (int32_t)wa_ctr_draw(antkey, (uint32_t)step);
+                    double rnd = (double)rv / (double)2147483647;
+                    const double *row = info + (int64_t)r * ld;
+                    double sum = 0;
+                    for (int32_t c0 = 0; c0 < ncol; c0 += 16) {  // 16 cities per batch: 16 independent LDS reads
+                        const uint32_t m16 = (uint32_t)(J[NW == 1 ? 0 : (c0 >> 6)] >> (c0 & 63));
+#pragma unroll
+                        for (int32_t i = 0; i < 16; i++) {
+                            sum = __builtin_fma(row[c0 + i], wa_bit_as_double(m16, i), sum);
+                            if (PREFIX) prefix[c0 + i] = sum;
+                        }
+                    }
+                    rnd *= sum;
+                    if (PREFIX) {
+                        // sum_prob of the second pass (:135-141) takes exactly the values prefix[c]: find the
+                        // first c with prefix[c] >= rnd (non-decreasing: terms are >= 0), then the first
+                        // unvisited city at or after it (prefix is flat over visited cities)
+                        int32_t idx = 0;  // columns >= ncol were never written this step: treat them as +inf
+#pragma unroll
+                        for (int32_t half = 32 * NW; half > 0; half >>= 1)
+                            if (idx + half - 1 < ncol && prefix[idx + half - 1] < rnd) idx += half;
+                        if (idx < ncol && prefix[idx] >= rnd) {
+#pragma unroll
+                            for (int w = NW - 1; w >= 0; w--) {
+                                const int32_t lo = idx - w * 64;
+                                const unsigned long long m = lo >= 64 ? 0ULL : (lo <= 0 ? J[w] : (J[w] & (~0ULL << lo)));
+                                if (m) next = w * 64 + (__ffsll((long long)m) - 1);
+                            }
+                        }
+                    } else {
+                        double sp = 0;
+                        bool found = false;
+                        for (int32_t c0 = 0; c0 < ncol; c0 += 16) {
+                            const uint32_t m16 = (uint32_t)(J[NW == 1 ? 0 : (c0 >> 6)] >> (c0 & 63));
+#pragma unroll
+                            for (int32_t i = 0; i < 16; i++) {
+                                sp = __builtin_fma(row[c0 + i], wa_bit_as_double(m16, i), sp);
+                                if (!found && ((m16 >> i) & 1u) && sp >= rnd) { next = c0 + i; found = true; }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    if ((next >> 6) == w) {
+                        const unsigned long long bit = 1ULL << (next & 63);
+                        if (J[w] & bit) { J[w] &= ~bit; left--; }  // J[k].erase(next) :153
+                    }
+                tours[(int64_t)k * n + step] = next;
+                if (step < n - 1) L += r == next ? 0.0 : dist[(int64_t)r * n + next];  // calc :36-44
+                r = next;
+            }
+            s_L[k] = L;
+        }
+        __syncthreads();
+        if (tid == 0) {  // update_pheromone :163-174: first strictly smallest tour
+            double nowL = INF;
+            int32_t nowk = -1;
+            for (int32_t a = 0; a < n; a++)
+                if (s_L[a] < nowL) { nowL = s_L[a]; nowk = a; }
+            s_nowL = nowL;
+            s_nowk = nowk;
+        }
+        __syncthreads();
+        const int32_t nowk = s_nowk;
+        if (nowk >= 0 && s_nowL < s_bestL)  // best = now_best :171-174, stored as (r, s) edges
+            for (int32_t e = tid; e < n; e += blockDim.x) {
+                best[2 * e] = e == 0 ? nowk : tours[(int64_t)nowk * n + e - 1];
+                best[2 * e + 1] = tours[(int64_t)nowk * n + e];
+            }
+        for (int64_t e = tid; e < nn; e += blockDim.x) pher[e] *= (1 - alpha);  // :175-177
+        __syncthreads();
+        if (tid == 0) {
+            if (nowk >= 0) {
+                if (s_nowL < s_bestL) s_bestL = s_nowL;
+                int32_t a = nowk;
+                for (int32_t e = 0; e < n; e++) {  // :179-184, all n edges incl. the closing one
+                    const int32_t b = tours[(int64_t)nowk * n + e];
+                    pher[(int64_t)a * n + b] += 1. / (double)s_nowL;
+                    pher[(int64_t)b * n + a] = pher[(int64_t)a * n + b];
+                    a = b;
+                }
+            }
+            if (s_last > s_bestL) { s_last = s_bestL; s_bad = 0; }
+            else s_bad++;
+            s_it = it + 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        G.out_cost[inst] = s_bestL;
+        G.out_iters[inst] = s_it;
+        if (G.rng_mode == 0) {
+            for (int i = 0; i < 31; i++) G.rng->r[i] = rr[i];
+            G.rng->f = rf;
+            G.rng->b = rb;
+        }
+    }
+}

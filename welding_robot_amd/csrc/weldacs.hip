@@ -857,7 +857,7 @@ int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32
     e = e ? e : dalloc(&d_dist, I * nn);
     e = e ? e : dalloc(&G.pher, I * nn);
     e = e ? e : dalloc(&G.h6, I * nn);
-    e = e ? e : dalloc(&G.info, I * nn);
+    e = e ? e : dalloc(&G.info, I * (size_t)257 * n + I * nn);
     e = e ? e : dalloc(&G.antL, I * n);
     e = e ? e : dalloc(&G.tours, I * nn * 2);
     e = e ? e : dalloc(&G.best, I * n * 2);
@@ -881,8 +881,30 @@ int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32
     h = h ? h : hipMemcpyAsync(G.rng, &r, sizeof r, hipMemcpyHostToDevice, ctx->stream);
     h = h ? h : hipMemsetAsync(G.best, 0, sizeof(int32_t) * I * n * 2, ctx->stream);
     if (h == hipSuccess) {
-        k_gtsp<<<(unsigned)n_instances, 256, 0, ctx->stream>>>(G);
-        h = hipGetLastError();
+        // fast path: lanes = ants, info matrix in LDS (rows padded to the mask width, odd stride) when
+        // it fits; for n <= 64 the per-ant prefix sums live there too (binary-search second pass)
+        const int nw = n <= 64 ? 1 : (n <= 128 ? 2 : 4);
+        const size_t ld = (size_t)(64 * nw + 1);
+        const size_t info_bytes = sizeof(double) * ld * n;
+        const bool in_lds = info_bytes <= 140 * 1024;
+        const unsigned threads = (unsigned)(((n + 63) / 64) * 64);
+        const bool prefix = nw == 1;
+        if (n <= 256 && env_int("WA_GTSP_GENERIC", 0) == 0) {
+            size_t shm = (in_lds ? info_bytes : 0) + (prefix ? sizeof(double) * ld * threads : 0);
+#define WA_GTSP_LAUNCH(NW, LDS, PFX)                                                                                     \
+    do {                                                                                                                 \
+        h = hipFuncSetAttribute((const void *)k_gtsp_fast<NW, LDS, PFX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        if (h == hipSuccess) k_gtsp_fast<NW, LDS, PFX><<<(unsigned)n_instances, threads, shm, ctx->stream>>>(G);         \
+    } while (0)
+            if (nw == 1) WA_GTSP_LAUNCH(1, true, true);
+            else if (nw == 2 && in_lds) WA_GTSP_LAUNCH(2, true, false);
+            else if (nw == 2) WA_GTSP_LAUNCH(2, false, false);
+            else WA_GTSP_LAUNCH(4, false, false);
+#undef WA_GTSP_LAUNCH
+        } else {
+            k_gtsp<<<(unsigned)n_instances, 256, 0, ctx->stream>>>(G);
+        }
+        if (h == hipSuccess) h = hipGetLastError();
     }
     std::vector<double> cost(I);
     std::vector<int32_t> its(I);
