@@ -774,8 +774,8 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 // PUBLISHES what k_rank publishes (global best, perm/depA for the apply pass, trace, the next
 // generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
-__global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *__restrict__ src_base,
-                                                        float *__restrict__ dst_base, int32_t E, int32_t gen)
+__global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
+                                                        float *dst_base, int32_t E, int32_t gen)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
 // pheromone field is double-buffered so that this sweep (which only needs the field the walk
 // is READING) runs on a second stream concurrently with the latency-bound walk; src == dst is
 // allowed (in-place).  float4 per lane, 4 independent float4 in flight per thread, grid-stride.
-__global__ __launch_bounds__(256) void k_evaporate(const float *__restrict__ src_base, float *__restrict__ dst_base,
+__global__ __launch_bounds__(256) void k_evaporate(const float *src_base, float *dst_base,
                                                    int64_t stride, int64_t n_floats, float rho)
 {
     const float *src = src_base + (int64_t)blockIdx.y * stride;

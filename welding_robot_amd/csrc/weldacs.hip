@@ -46,7 +46,7 @@ struct wa_acs {
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     int cur_buf;
     WaRun R;
-    bool begun, overlap_walk, overlap_rank, fuse;
+    bool begun, overlap_walk, overlap_rank, fuse, inplace;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
@@ -385,6 +385,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->overlap_walk = env_int("WA_OVERLAP_WALK", 0) != 0;
     s->overlap_rank = env_int("WA_OVERLAP_RANK", 0) != 0;
     s->fuse = env_int("WA_FUSE", 1) != 0;
+    s->inplace = env_int("WA_EVAP_INPLACE", 0) != 0 && !s->overlap_walk;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
@@ -624,7 +625,7 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     for (int32_t g = 0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
         const int32_t gen = s->gens_enqueued;  // == the device-side generation counter since wa_acs_begin
-        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ 1];
+        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (s->inplace ? 0 : 1)];
         if (s->overlap_walk) {  // fork the sweep before the walk
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -643,7 +644,7 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         prof_close(s, e);
         if (fused) {  // DEV fast path: walk -> {sweep + rank + mark} -> apply
             launch_fused(s, src, dst, P, gen, sampled);
-            s->cur_buf ^= 1;
+            if (!s->inplace) s->cur_buf ^= 1;
             s->D.pher = dst;
             e = prof_open(s, WA_K_DEPOSIT, sampled);
             k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
@@ -670,7 +671,7 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             prof_close(s, e);
             launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
         }
-        s->cur_buf ^= 1;
+        if (!s->inplace) s->cur_buf ^= 1;
         s->D.pher = dst;
         e = prof_open(s, WA_K_DEPOSIT, sampled);
         for (int32_t c = 0; c < chunks; c++) {
