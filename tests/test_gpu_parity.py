@@ -418,3 +418,30 @@ def test_batched_pair_planning_matches_oracle_and_is_shard_invariant(ctx):
     t = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=seed)
     o = O.gtsp_solve(cost, mode=O.DEV, seed=seed)
     assert t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
+
+
+def test_best_path_replay_is_bit_identical_to_full_steps_at_full_size(ctx):
+    """C3 (128^3, 256 ants), 260 generations -- long past convergence, where nearly every step is a
+    replay step: the replay shortcut (WA_REPLAY=1, default) and the plain step loop (WA_REPLAY=0) must
+    produce the same traces, the same best path and the same pheromone field, bit for bit."""
+    og = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    dg = dgrid_from(ctx, og)
+    p = api.default_params(max_iteration=260, predict=731.43, fixed_colony=256, rng_mode=api.RNG_DEV, seed=12345)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["WA_REPLAY"] = mode
+        try:
+            s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=256)
+        finally:
+            del os.environ["WA_REPLAY"]
+        s.solve(p, 16513, 2097151)
+        out[mode] = (s.trace(), s.result(), s.pheromone())
+        s.close()
+    (ta, ra, pa), (tb, rb, pb) = out["1"], out["0"]
+    for k in ("bestL", "iterbestL"):
+        assert np.array_equal(bits(ta[k]), bits(tb[k])), k
+    for k in ("colony", "finite", "steps"):
+        assert np.array_equal(ta[k], tb[k]), k
+    assert bits(ra[0]) == bits(rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+    assert np.array_equal(bits(pa), bits(pb))
+    assert ta["steps"][-1] == 256 * (len(ra[1]) - 1)  # converged: every ant walks the best path

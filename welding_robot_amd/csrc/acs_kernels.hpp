@@ -21,7 +21,9 @@ struct WaAcsDev {
     float *pher, *heur;            // [slot][pher_stride]
     unsigned long long *mask;      // [slot][pher_stride]
     uint32_t *bestmark;            // [slot][n]
+    int32_t *bestpos;              // [slot][n]  index of a marked voxel on the best path
     int32_t *bestpath;             // [slot][path_cap]
+    float *rtab;                   // [slot][path_cap][8] replay table of the best path (see k_replay_table); may be null
     int32_t *paths;                // [slot][max_colony][path_cap]
     float *antL;                   // [slot][max_colony]
     int32_t *antLen;               // [slot][max_colony]
@@ -197,6 +199,19 @@ __device__ __forceinline__ float dpp_from_above(float x)
 #define WA_STAMP(i) do { } while (0)
 #endif
 
+// The two ORDERED fp32 sums of selectNext over the (zero-padded) candidate values `a` of one 8-lane
+// group: t -> role 5 holds total = ((((0+a0)+a1)+...)+a5) (:155); c -> role i holds prob_sum after adding
+// candidates 5..i (:172-177).  One definition for the walk step and for the replay table, so the bits agree.
+__device__ __forceinline__ void wa_ordered_sums(float a, float &t, float &c)
+{
+    t = 0.f + a;
+#pragma unroll
+    for (int i = 0; i < 5; i++) t = dpp_from_below(t) + a;
+    c = 0.f + a;
+#pragma unroll
+    for (int i = 0; i < 5; i++) c = dpp_from_above(c) + a;
+}
+
 struct WaWalkState {
     int32_t cur, len;
     uint32_t step;
@@ -217,7 +232,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
                                              int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
                                              int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
                                              int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out,
-                                             unsigned long long *dbg)
+                                             unsigned long long *dbg, const int32_t *prefix_words)
 {
     // Lane layout: group j = lane >> 3 (j < 6), role k2 = lane & 7 (k2 < 6).  Every step, group j
     // PREFETCHES the pheromone/heuristic record of neighbour j of the current voxel (36 lanes x 2
@@ -243,7 +258,10 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     const uint32_t hk_const = (uint32_t)dk * 2654435761u;
     int32_t cur = st.cur, len = st.len;      // the step about to be taken is step number len - 1
     float L = st.L;
-    int32_t pbuf = st.cur;   // lane (i & 63) holds path word i of the current 64-entry block
+    // lane (i & 63) holds path word i of the current 64-entry block; when the walk resumes after a
+    // replayed prefix the already-written part of that block comes from the prefix
+    int32_t pbuf = st.cur;
+    if (prefix_words) pbuf = lane < (st.len & 63) ? prefix_words[(st.len & ~63) + lane] : 0;
     int grp = 0;             // group holding the record of `cur`
     float ublock = 0.f;      // DEV: lane i holds the uniform draw of the step with (len & 63) == i
     float pp = -0.f, ph = 0.f;
@@ -290,15 +308,9 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
         const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
         const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
-        // total = ((((0 + a0) + a1) + ...) + a5)   (:155)   -> role 5 of the active group
-        float t = 0.f + a;
-#pragma unroll
-        for (int i = 0; i < 5; i++) t = dpp_from_below(t) + a;
+        float t, c;  // total -> role 5 of the active group; prob_sum after candidate i -> role i
+        wa_ordered_sums(a, t, c);
         const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), grp * 8 + 5));
-        // prob_sum after adding candidate i, accumulated from i = 5 downwards (:172-177) -> role i
-        float c = 0.f + a;
-#pragma unroll
-        for (int i = 0; i < 5; i++) c = dpp_from_above(c) + a;
         WA_STAMP(3);                                   // admissibility + both ordered scans
         float rnd;                                     // (float)rand() / (float)RAND_MAX, RAND_MAX -> 2^31 (:169)
         if (MODE == 1) {                               // DEV draws are pure functions of (ant, step): 64 at a
@@ -447,16 +459,88 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
     st.done = true;
 }
 
+// ------------------------------------------------------------------ replay of the best path
+// While an ant has followed the global-best path from the start, its visited set is exactly the
+// path prefix, so admissibility, info, `total` and the cumulative thresholds at node i are the
+// same for every such ant: k_replay_table computes them once per generation, and the ant only has
+// to check that its own draw picks the path's edge:  rnd = u * total;  first i (from 5 down) with
+// thr[i] >= rnd  ==  next_k ?   Bit-identical to taking the full step (same operands, same order,
+// same draw), about a fifth of the instructions.  At the first node where the draw picks another
+// edge the ant rebuilds its tabu hash from the prefix and continues in the general loop, which
+// recomputes that step in full.  After convergence nearly every step of every ant is a replay step.
+// Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).
+__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node)
+{
+    // Replay steps do not depend on each other while the ant stays on the path, so 8 consecutive
+    // nodes are checked at once: one coalesced 256-byte load brings T[8c .. 8c+7][8] with node 8c+g in
+    // lane group g; every group forms its own draw (a pure function of the step number = node
+    // index), its own rnd = u * total, and asks "would this ant NOT take the path's edge here?".
+    // The first set bit of that ballot is the first node where the ant leaves the path (or dies).
+    const int lane = threadIdx.x;
+    const int role = lane & 7;
+    const bool thr_lane = role < 6;
+    const int tot_src = (lane & 0x38) | 6, nk_src = (lane & 0x38) | 7;
+    float tcur = T[lane];
+    float tnext = 8 < rlen ? T[64 + lane] : 0.f;
+    int32_t i0 = 0;
+    for (;;) {
+        const int32_t nodev = i0 + (lane >> 3);
+        const bool valid = thr_lane && nodev < rlen - 1;  // decisions exist at nodes 0 .. rlen-2
+        float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
+        const float total = __shfl(tcur, tot_src);
+        const int nk = __float_as_int(__shfl(tcur, nk_src));
+        rnd *= total;                                      // :170
+        const bool hit = valid && tcur >= rnd;             // thr = admissible ? prob_sum : -inf   (:178)
+        // scanning i = 5..0 the first hit must be the path's edge nk: a hit above nk deviates, no hit at nk
+        // means either a lower edge is taken or nothing is (dead end)
+        const bool fail = valid && ((hit && role > nk) || (role == nk && !hit));
+        const unsigned long long fm = __ballot(fail);
+        if (__builtin_expect(fm != 0, 0)) {
+            const int g = (__ffsll((long long)fm) - 1) >> 3;
+            const unsigned long long hm = __ballot(hit);
+            node = i0 + g;
+            return ((hm >> (8 * g)) & 0x3fULL) ? 3 : 1;
+        }
+        i0 += 8;
+        if (i0 >= rlen - 1) { node = rlen - 1; return 2; }  // every decision up to the last node followed the path
+        tcur = tnext;                                        // keep one chunk in flight
+        tnext = i0 + 8 < rlen ? T[((i0 >> 3) + 1) * 64 + lane] : 0.f;
+    }
+}
+
 template <int MODE, bool ALPHA1>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
-                                            int32_t *flags_out)
+                                            int32_t *flags_out, int32_t rlen, float bestL)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    WaWalkState st;
+    st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
+    const int32_t *prefix_words = nullptr;
+    if (MODE == 1 && rlen > 1) {
+        int32_t node = 0;
+        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
+        st.len = node + 1;
+        for (int32_t q = lane; q < st.len; q += 64) path[q] = bpath[q];  // the walked prefix IS the best path's
+        if (what != 3) {  // finished on the replay track
+            // arriving over the whole best path accumulates exactly the steps that produced best.L
+            const float L = what == 2 ? bestL : INFINITY;
+            if (lane == 0) {
+                D.antL[(int64_t)slot * D.max_colony + ant] = L;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+            }
+            return;
+        }
+        st.cur = bpath[node] & (int32_t)WA_ID_MASK;
+        st.step = (uint32_t)node;                                // steps taken so far = draws consumed
+        for (int32_t q = 0; q < node; q++) st.L += R.precision;  // :78, one add per step taken
+        prefix_words = bpath;
+    }
     WaTabu T;
     T.tab = tab;
     T.mask = (1u << hash_log2) - 1u;
@@ -468,16 +552,74 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
     for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) tabu_insert(T, start);  // addStartNode :81-86 (path[0] is buffered by the fast loop)
+    if (prefix_words && st.len <= spill_at) {  // (a longer prefix goes straight to the spilled slow loop)
+        // tabu set := the replayed prefix.  Distinct keys, no deletions: any insertion order gives a valid
+        // open-addressing table, so the lanes insert concurrently with compare-and-swap on the slot.
+        for (int32_t q = lane; q < st.len; q += 64) {
+            const int32_t key = bpath[q] & (int32_t)WA_ID_MASK;
+            uint32_t h = ((uint32_t)key * 2654435761u) >> T.shift;
+            while (atomicCAS(&tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & T.mask;
+        }
+    } else if (!prefix_words && lane == 0) {
+        tabu_insert(T, start);  // addStartNode :81-86 (path[0] is buffered by the fast loop)
+    }
     __builtin_amdgcn_wave_barrier();
-    WaWalkState st;
-    st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
-    wa_walk_fast<MODE, ALPHA1>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey, rng_r, rng_f,
-                       rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr);
+    const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
+    if (st.len < fast_limit)
+        wa_walk_fast<MODE, ALPHA1>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
+                                   rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
+    else if (st.len >= (int32_t)D.path_cap) {  // cannot happen after a replay (the best path fits), kept for symmetry
+        if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+        st.L = INFINITY;
+        st.done = true;
+    } else if (!prefix_words && lane == 0) {
+        path[0] = start;  // the slow loop reads the path back from memory
+    }
     if (!st.done) wa_walk_slow<MODE>(D, R, pher, heur, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+    }
+}
+
+// ------------------------------------------------------------------ replay table of the best path
+// One 16-lane row per best-path node i (roles 0..5 = the six edges): the walk's own step evaluation with
+// visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i.
+// Output per node: thr[k] = admissible ? prob_sum_k : -inf (k = 0..5), total, edge taken to best[i+1].
+__global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
+{
+    const int32_t slot = blockIdx.y;
+    const WaSlotCtl *ctl = &D.ctl[slot];
+    if (ctl->bestL == INFINITY) return;
+    const int32_t blen = ctl->best_len;
+    const uint32_t ver = ctl->best_ver;
+    const int32_t k2 = threadIdx.x & 15;
+    const int32_t row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, rows = (gridDim.x * blockDim.x) >> 4;
+    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
+    for (int32_t i = row0; i < blen; i += rows) {
+        const int32_t v = bpath[i] & (int32_t)WA_ID_MASK;
+        float p = -0.f, h = 0.f;
+        bool adm = false;
+        if (k2 < 6) {
+            p = pher[(int64_t)v * 6 + k2];
+            h = heur[(int64_t)v * 6 + k2];
+            if ((__float_as_uint(p) >> 31) == 0) {  // in bounds and free (:148)
+                const int32_t nb = v + wa_delta(k2, D.d.nx, D.d.nxy);
+                adm = !(mark[nb] == ver && pos[nb] <= i);  // not on the prefix best[0..i] (:145-146)
+            }
+        }
+        const float info = (R.alpha == 1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
+        const float a = adm ? info : 0.f;
+        float t, c;
+        wa_ordered_sums(a, t, c);
+        if (k2 < 6) T[(int64_t)i * 8 + k2] = adm ? c : -INFINITY;
+        if (k2 == 5) T[(int64_t)i * 8 + 6] = t;
+        if (k2 == 0) T[(int64_t)i * 8 + 7] = __int_as_float(i + 1 < blen ? (int32_t)((uint32_t)bpath[i + 1] >> WA_K_SHIFT) : -1);
     }
 }
 
@@ -492,7 +634,9 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0;
-    wa_walk_one<1, ALPHA1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+    const float bestL = c->bestL;
+    const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
+    wa_walk_one<1, ALPHA1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -511,7 +655,7 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
+        wa_walk_one<0, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
@@ -697,11 +841,13 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
         const int32_t *src = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
         int32_t *dst = D.bestpath + (int64_t)slot * D.path_cap;
         uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+        int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
         ver = ver + 1;
         for (int32_t i = tid; i < blen; i += blockDim.x) {
             int32_t w = src[i];
             dst[i] = w;
             mark[w & WA_ID_MASK] = ver;
+            pos[w & WA_ID_MASK] = i;
         }
         bestL = iterL;
         if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; }
@@ -865,11 +1011,13 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
             int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
             uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+            int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
             ver = ver + 1;
             for (int32_t i = tid; i < blen; i += blockDim.x) {
                 int32_t w = srcp[i];
                 dstp[i] = w;
                 mark[w & WA_ID_MASK] = ver;
+                pos[w & WA_ID_MASK] = i;
             }
             bestL = iterL;
         }

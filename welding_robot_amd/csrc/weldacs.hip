@@ -394,6 +394,8 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     e = e ? e : dalloc(&D.mask, S * D.pher_stride);
     e = e ? e : dalloc(&D.bestmark, S * n);
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
+    e = e ? e : dalloc(&D.bestpos, S * n);
+    if (env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8);
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
     e = e ? e : dalloc(&D.antLen, S * C);
@@ -447,7 +449,7 @@ void wa_acs_destroy(wa_acs *s)
     hipStreamSynchronize(s->ctx->stream);
     for (auto &p : s->ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     WaAcsDev &D = s->D;
-    hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath);
+    hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.rtab);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
     hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
@@ -648,6 +650,7 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             s->D.pher = dst;
             e = prof_open(s, WA_K_DEPOSIT, sampled);
             k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
+            if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
             prof_close(s, e);
             s->gens_enqueued++;
             continue;
@@ -679,6 +682,7 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             k_deposit_mark<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
             k_deposit_apply<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
         }
+        if (s->D.rtab && s->R.rng_mode == WA_RNG_DEV) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
         prof_close(s, e);
         s->gens_enqueued++;
     }
