@@ -469,19 +469,30 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
 // edge the ant rebuilds its tabu hash from the prefix and continues in the general loop, which
 // recomputes that step in full.  After convergence nearly every step of every ant is a replay step.
 // Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).
-__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node)
+__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, float *lds_t, int32_t lds_floats, int32_t rlen,
+                                              uint64_t antkey, int32_t &node)
 {
     // Replay steps do not depend on each other while the ant stays on the path, so 8 consecutive
-    // nodes are checked at once: one coalesced 256-byte load brings T[8c .. 8c+7][8] with node 8c+g in
-    // lane group g; every group forms its own draw (a pure function of the step number = node
-    // index), its own rnd = u * total, and asks "would this ant NOT take the path's edge here?".
-    // The first set bit of that ballot is the first node where the ant leaves the path (or dies).
+    // nodes are checked at once: chunk c = T[8c .. 8c+7][8] has node 8c+g in lane group g; every
+    // group forms its own draw (a pure function of the step number = node index), its own
+    // rnd = u * total, and asks "would this ant NOT take the path's edge here?".  The first set bit
+    // of that ballot is the first node where the ant leaves the path (or dies).
+    // The table (32 B per node) is first staged into the LDS the tabu hash will use later -- all
+    // its loads in flight at once -- so the chunk loop reads LDS instead of paying one global
+    // round trip per 8 nodes; paths longer than the staging area stream from global memory.
     const int lane = threadIdx.x;
     const int role = lane & 7;
     const bool thr_lane = role < 6;
     const int tot_src = (lane & 0x38) | 6, nk_src = (lane & 0x38) | 7;
-    float tcur = T[lane];
-    float tnext = 8 < rlen ? T[64 + lane] : 0.f;
+    const int32_t n_floats = rlen * 8;
+    const bool staged = n_floats <= lds_floats;
+    if (staged) {
+        for (int32_t q = lane; q < n_floats; q += 64) lds_t[q] = T[q];
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float *src = staged ? lds_t : T;
+    float tcur = src[lane];  // (entries past rlen are never used: `valid` masks them)
+    float tnext = 8 < rlen ? src[64 + lane] : 0.f;
     int32_t i0 = 0;
     for (;;) {
         const int32_t nodev = i0 + (lane >> 3);
@@ -504,7 +515,7 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32
         i0 += 8;
         if (i0 >= rlen - 1) { node = rlen - 1; return 2; }  // every decision up to the last node followed the path
         tcur = tnext;                                        // keep one chunk in flight
-        tnext = i0 + 8 < rlen ? T[((i0 >> 3) + 1) * 64 + lane] : 0.f;
+        tnext = i0 + 8 < rlen ? src[((i0 >> 3) + 1) * 64 + lane] : 0.f;
     }
 }
 
@@ -524,7 +535,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     const int32_t *prefix_words = nullptr;
     if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
-        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
+        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, reinterpret_cast<float *>(tab), 1 << hash_log2, rlen,
+                                        antkey, node);
         st.len = node + 1;
         for (int32_t q = lane; q < st.len; q += 64) path[q] = bpath[q];  // the walked prefix IS the best path's
         if (what != 3) {  // finished on the replay track
