@@ -1130,13 +1130,18 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
 {
     const int32_t slot = blockIdx.z, bit = blockIdx.y, o = base + bit + 1;
     const WaSlotCtl *c = &D.ctl[slot];
-    if (o > c->n_dep) return;
+    const int32_t n_dep = c->n_dep;
+    if (o > n_dep) return;
+    // the <= 64 per-rank coefficients of this chunk, staged once per block: the owner of an edge adds
+    // one of them per rank bit, in ascending rank order
+    __shared__ float s_dep[64];
+    if (threadIdx.x < 64) s_dep[threadIdx.x] = base + (int32_t)threadIdx.x < n_dep ? D.depA[(int64_t)slot * D.max_colony + base + threadIdx.x] : 0.f;
+    __syncthreads();
     const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
     const int32_t len = D.antLen[(int64_t)slot * D.max_colony + a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    const float *depA = D.depA + (int64_t)slot * D.max_colony;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
     const uint32_t ver = c->best_ver;
     const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
@@ -1147,11 +1152,12 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
         unsigned long long m = mask[e];
         if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
         bool onbest = mark[v] == ver && mark[w & WA_ID_MASK] == ver;  // :209
+        const float bonus = (float)onbest * lambda * Q / bestL;       // second term of :211, the same for every rank
         float p = pher[e];
         while (m) {
             int b = __ffsll((long long)m) - 1;
             m &= m - 1;
-            p += depA[base + b] + (float)onbest * lambda * Q / bestL;  // :210-211
+            p += s_dep[b] + bonus;  // :210-211
         }
         pher[e] = p;
         mask[e] = 0;
