@@ -491,31 +491,36 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, float
         __builtin_amdgcn_wave_barrier();
     }
     const float *src = staged ? lds_t : T;
-    float tcur = src[lane];  // (entries past rlen are never used: `valid` masks them)
-    float tnext = 8 < rlen ? src[64 + lane] : 0.f;
-    int32_t i0 = 0;
-    for (;;) {
-        const int32_t nodev = i0 + (lane >> 3);
+    // one 8-node chunk: returns the ballot of lanes that would NOT follow the path (0 = all 8 nodes follow)
+    auto check = [&](float tv, int32_t base, unsigned long long &hit_mask) -> unsigned long long {
+        const int32_t nodev = base + (lane >> 3);
         const bool valid = thr_lane && nodev < rlen - 1;  // decisions exist at nodes 0 .. rlen-2
         float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
-        const float total = __shfl(tcur, tot_src);
-        const int nk = __float_as_int(__shfl(tcur, nk_src));
+        const float total = __shfl(tv, tot_src);
+        const int nk = __float_as_int(__shfl(tv, nk_src));
         rnd *= total;                                      // :170
-        const bool hit = valid && tcur >= rnd;             // thr = admissible ? prob_sum : -inf   (:178)
+        const bool hit = valid && tv >= rnd;               // thr = admissible ? prob_sum : -inf   (:178)
         // scanning i = 5..0 the first hit must be the path's edge nk: a hit above nk deviates, no hit at nk
         // means either a lower edge is taken or nothing is (dead end)
         const bool fail = valid && ((hit && role > nk) || (role == nk && !hit));
-        const unsigned long long fm = __ballot(fail);
-        if (__builtin_expect(fm != 0, 0)) {
+        hit_mask = __ballot(hit);
+        return __ballot(fail);
+    };
+    // two independent chunks per iteration so that their LDS reads, shuffles and draws overlap
+    for (int32_t i0 = 0;; i0 += 16) {
+        const float ta = src[(i0 >> 3) * 64 + lane];  // (entries past rlen are never used: `valid` masks them;
+        const float tb = i0 + 8 < rlen ? src[((i0 >> 3) + 1) * 64 + lane] : 0.f;  //  the staging area / table is large enough)
+        unsigned long long ha, hb;
+        const unsigned long long fa = check(ta, i0, ha);
+        const unsigned long long fb = check(tb, i0 + 8, hb);
+        if (__builtin_expect((fa | fb) != 0, 0)) {
+            const bool in_a = fa != 0;
+            const unsigned long long fm = in_a ? fa : fb, hm = in_a ? ha : hb;
             const int g = (__ffsll((long long)fm) - 1) >> 3;
-            const unsigned long long hm = __ballot(hit);
-            node = i0 + g;
+            node = i0 + (in_a ? 0 : 8) + g;
             return ((hm >> (8 * g)) & 0x3fULL) ? 3 : 1;
         }
-        i0 += 8;
-        if (i0 >= rlen - 1) { node = rlen - 1; return 2; }  // every decision up to the last node followed the path
-        tcur = tnext;                                        // keep one chunk in flight
-        tnext = i0 + 8 < rlen ? src[((i0 >> 3) + 1) * 64 + lane] : 0.f;
+        if (i0 + 16 >= rlen - 1) { node = rlen - 1; return 2; }  // every decision up to the last node followed the path
     }
 }
 

@@ -395,7 +395,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     e = e ? e : dalloc(&D.bestmark, S * n);
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
     e = e ? e : dalloc(&D.bestpos, S * n);
-    if (env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8);
+    if (env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8 + 256);  // + slack: the replay reads whole 16-node chunks
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
     e = e ? e : dalloc(&D.antLen, S * C);
