@@ -22,6 +22,7 @@ struct WaAcsDev {
     unsigned long long *mask;      // [slot][pher_stride]
     uint32_t *bestmark;            // [slot][n]
     int32_t *bestpos;              // [slot][n]  index of a marked voxel on the best path
+    uint8_t *besttabu;             // [slot][path_cap] bit k: neighbour k of best[i] lies on the prefix best[0..i]
     int32_t *bestpath;             // [slot][path_cap]
     float *rtab;                   // [slot][path_cap][8] replay table of the best path (see k_replay_table); may be null
     int32_t *paths;                // [slot][max_colony][path_cap]
@@ -29,8 +30,7 @@ struct WaAcsDev {
     int32_t *antLen;               // [slot][max_colony]
     int32_t *perm;                 // [slot][max_colony]   rank o-1 -> ant
     float *depA;                   // [slot][max_colony]   (lambda-o)*Q/L of rank o
-    float *sortk;                  // [slot][max_colony]   REF introsort scratch
-    int32_t *sortt;
+    float *sortk;                  // [slot][2*max_colony] REF introsort scratch (key, tag records)
     uint32_t *vbits;               // [slot][max_colony][vbits_words] spill tabu bitmap (all zero at rest)
     WaSlotCtl *ctl;                // [slot]
     WaGlibcRand *rng;              // REF stream (one per solver, like the process-global rand())
@@ -601,7 +601,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 
 // ------------------------------------------------------------------ replay table of the best path
 // One 16-lane row per best-path node i (roles 0..5 = the six edges): the walk's own step evaluation with
-// visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i.
+// visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i (bits
+// precomputed by wa_best_prefix_tabu whenever the best path changes).
 // Output per node: thr[k] = admissible ? prob_sum_k : -inf (k = 0..5), total, edge taken to best[i+1].
 __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 {
@@ -609,12 +610,10 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
     const WaSlotCtl *ctl = &D.ctl[slot];
     if (ctl->bestL == INFINITY) return;
     const int32_t blen = ctl->best_len;
-    const uint32_t ver = ctl->best_ver;
     const int32_t k2 = threadIdx.x & 15;
     const int32_t row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, rows = (gridDim.x * blockDim.x) >> 4;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
-    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
-    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+    const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
@@ -625,10 +624,8 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
         if (k2 < 6) {
             p = pher[(int64_t)v * 6 + k2];
             h = heur[(int64_t)v * 6 + k2];
-            if ((__float_as_uint(p) >> 31) == 0) {  // in bounds and free (:148)
-                const int32_t nb = v + wa_delta(k2, D.d.nx, D.d.nxy);
-                adm = !(mark[nb] == ver && pos[nb] <= i);  // not on the prefix best[0..i] (:145-146)
-            }
+            // in bounds and free (:148), and not on the prefix best[0..i] (:145-146)
+            adm = (__float_as_uint(p) >> 31) == 0 && !((btabu[i] >> k2) & 1u);
         }
         const float info = (R.alpha == 1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
         const float a = adm ? info : 0.f;
@@ -796,6 +793,34 @@ __device__ inline void wa_std_sort(WaRec *v, int32_t n)
     } else ss_insertion_sort(v, v + n);
 }
 
+// After the best path was re-stamped (mark/pos) by THIS block: for every node i, which of its six
+// neighbours already lie on the prefix best[0..i].  Static per best path, so it is computed here --
+// a few times per run -- instead of two dependent gathers per node in every generation's
+// k_replay_table.
+__device__ __forceinline__ void wa_best_prefix_tabu(const WaAcsDev &D, int32_t slot, int32_t blen, uint32_t ver)
+{
+    __syncthreads();  // the block's own mark/pos stores are visible to all of its threads
+    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+    uint8_t *bt = D.besttabu + (int64_t)slot * D.path_cap;
+    for (int32_t i = threadIdx.x; i < blen; i += blockDim.x) {
+        const int32_t v = bpath[i] & (int32_t)WA_ID_MASK;
+        const int32_t x = v % D.d.nx, y = (v / D.d.nx) % D.d.ny, z = v / D.d.nxy;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
+                          Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
+            if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+                const int32_t nb = v + wa_delta(k, D.d.nx, D.d.nxy);
+                if (mark[nb] == ver && pos[nb] <= i) bits |= 1u << k;
+            }
+        }
+        bt[i] = (uint8_t)bits;
+    }
+}
+
 // ------------------------------------------------------------------ rank
 // one workgroup per problem: iteration best -> global best (strict <, first ant wins :263-264),
 // ranking (:273-275), per-rank deposit coefficient, trace, next generation's parameters.
@@ -866,6 +891,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
             mark[w & WA_ID_MASK] = ver;
             pos[w & WA_ID_MASK] = i;
         }
+        wa_best_prefix_tabu(D, slot, blen, ver);
         bestL = iterL;
         if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; }
     }
@@ -1036,6 +1062,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
                 mark[w & WA_ID_MASK] = ver;
                 pos[w & WA_ID_MASK] = i;
             }
+            wa_best_prefix_tabu(D, slot, blen, ver);
             bestL = iterL;
         }
         if (tid == 0) {

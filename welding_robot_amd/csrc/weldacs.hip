@@ -237,12 +237,15 @@ int wa_grid_from_mesh(wa_ctx *ctx, const float *tris, int64_t n_tris, float prec
     if (rc) return rc;
     float *d_tris = nullptr;
     if (dalloc(&d_tris, (size_t)n_tris * 12)) { wa_grid_destroy(g); return fail(ctx, WA_ERR_ALLOC, "triangle buffer"); }
-    HIPC(ctx, hipMemcpyAsync(d_tris, tris, sizeof(float) * 12 * n_tris, hipMemcpyHostToDevice, ctx->stream));
-    unsigned blocks = (unsigned)((g->d.n + 255) / 256);
-    k_voxelize<<<blocks, 256, 0, ctx->stream>>>(d_tris, n_tris, precision, g->d, g->cx, g->cy, g->cz, g->occ);
-    HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t ve = hipMemcpyAsync(d_tris, tris, sizeof(float) * 12 * n_tris, hipMemcpyHostToDevice, ctx->stream);
+    if (ve == hipSuccess) {
+        unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+        k_voxelize<<<blocks, 256, 0, ctx->stream>>>(d_tris, n_tris, precision, g->d, g->cx, g->cy, g->cz, g->occ);
+        ve = hipGetLastError();
+    }
+    if (ve == hipSuccess) ve = hipStreamSynchronize(ctx->stream);
     hipFree(d_tris);
+    if (ve != hipSuccess) { wa_grid_destroy(g); return fail(ctx, WA_ERR_DEVICE, "voxelise: %s", hipGetErrorString(ve)); }
     rc = grid_count_free(g);
     if (rc) { wa_grid_destroy(g); return rc; }
     *out = g;
@@ -395,6 +398,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     e = e ? e : dalloc(&D.bestmark, S * n);
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
     e = e ? e : dalloc(&D.bestpos, S * n);
+    e = e ? e : dalloc(&D.besttabu, S * path_capacity);
     if (env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8 + 256);  // + slack: the replay reads whole 16-node chunks
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
@@ -449,7 +453,7 @@ void wa_acs_destroy(wa_acs *s)
     hipStreamSynchronize(s->ctx->stream);
     for (auto &p : s->ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     WaAcsDev &D = s->D;
-    hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.rtab);
+    hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.besttabu); hipFree(D.rtab);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
     hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
