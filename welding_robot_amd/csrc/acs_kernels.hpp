@@ -604,17 +604,25 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 // visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i (bits
 // precomputed by wa_best_prefix_tabu whenever the best path changes).
 // Output per node: thr[k] = admissible ? prob_sum_k : -inf (k = 0..5), total, edge taken to best[i+1].
-__global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
+__device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
+                                              bool skip_best_src, float *s_dep);
+
+// apply_here: the row also APPLIES the pending ranked deposits (mask != 0) of its six edges -- same adds, same
+// ascending rank order as wa_apply_body -- writes them back, clears the masks, and evaluates on the new values.
+__device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t row0, int32_t rows, bool apply_here,
+                                              const float *s_dep)
 {
-    const int32_t slot = blockIdx.y;
     const WaSlotCtl *ctl = &D.ctl[slot];
     if (ctl->bestL == INFINITY) return;
     const int32_t blen = ctl->best_len;
+    const uint32_t ver = ctl->best_ver;
+    const float lambda = ctl->dep_lambda, Q = ctl->dep_Q, bestL = ctl->dep_bestL;
     const int32_t k2 = threadIdx.x & 15;
-    const int32_t row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, rows = (gridDim.x * blockDim.x) >> 4;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
-    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
     for (int32_t i = row0; i < blen; i += rows) {
@@ -622,8 +630,23 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
         float p = -0.f, h = 0.f;
         bool adm = false;
         if (k2 < 6) {
-            p = pher[(int64_t)v * 6 + k2];
-            h = heur[(int64_t)v * 6 + k2];
+            const int64_t e = (int64_t)v * 6 + k2;
+            p = pher[e];
+            h = heur[e];
+            if (apply_here) {
+                unsigned long long m = mask[e];
+                if (m) {  // somebody walked (v, k2): the neighbour is in bounds
+                    const bool onbest = mark[v + wa_delta(k2, D.d.nx, D.d.nxy)] == ver;  // v itself is on the best path (:209)
+                    const float bonus = (float)onbest * lambda * Q / bestL;
+                    while (m) {
+                        int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        p += s_dep[b] + bonus;  // :210-211
+                    }
+                    pher[e] = p;
+                    mask[e] = 0;
+                }
+            }
             // in bounds and free (:148), and not on the prefix best[0..i] (:145-146)
             adm = (__float_as_uint(p) >> 31) == 0 && !((btabu[i] >> k2) & 1u);
         }
@@ -635,6 +658,31 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
         if (k2 == 5) T[(int64_t)i * 8 + 6] = t;
         if (k2 == 0) T[(int64_t)i * 8 + 7] = __int_as_float(i + 1 < blen ? (int32_t)((uint32_t)bpath[i + 1] >> WA_K_SHIFT) : -1);
     }
+}
+
+__global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
+{
+    wa_table_rows(D, R, blockIdx.y, (blockIdx.x * blockDim.x + threadIdx.x) >> 4, (gridDim.x * blockDim.x) >> 4, false, nullptr);
+}
+
+// Deposit apply + replay table in ONE launch (DEV fast path, <= 64 depositing ranks): blocks [0, TB) are
+// table rows that also apply the deposits on every edge leaving a best-path node -- the only values
+// the table depends on -- and blocks [TB, TB + 8*64) are the ordinary apply pass, which skips exactly
+// those edges.  The two roles touch disjoint edges, so no ordering between them is needed.
+#define WA_TABLE_BLOCKS 32
+__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
+{
+    __shared__ float s_dep[64];
+    const int32_t slot = blockIdx.y;
+    if ((int32_t)blockIdx.x < WA_TABLE_BLOCKS) {
+        const int32_t n_dep = D.ctl[slot].n_dep;
+        if (threadIdx.x < 64) s_dep[threadIdx.x] = (int32_t)threadIdx.x < n_dep ? D.depA[(int64_t)slot * D.max_colony + threadIdx.x] : 0.f;
+        __syncthreads();
+        wa_table_rows(D, R, slot, (blockIdx.x * blockDim.x + threadIdx.x) >> 4, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep);
+        return;
+    }
+    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..511: (bx = ab & 7, rank bit = ab >> 3)
+    wa_apply_body(D, slot, 0, ab >> 3, ab & 7, 8, true, s_dep);
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
@@ -1158,15 +1206,15 @@ __global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
         atomicOr(&mask[e], 1ULL << bit);
     }
 }
-__global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
+// Body of the apply pass for rank bit `bit` of chunk `base`, x-block `bx` of `nbx`.  skip_best_src: edges that
+// leave a best-path node belong to the replay-table rows of the same launch (k_apply_table).
+__device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
+                                              bool skip_best_src, float *s_dep)
 {
-    const int32_t slot = blockIdx.z, bit = blockIdx.y, o = base + bit + 1;
+    const int32_t o = base + bit + 1;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t n_dep = c->n_dep;
     if (o > n_dep) return;
-    // the <= 64 per-rank coefficients of this chunk, staged once per block: the owner of an edge adds
-    // one of them per rank bit, in ascending rank order
-    __shared__ float s_dep[64];
     if (threadIdx.x < 64) s_dep[threadIdx.x] = base + (int32_t)threadIdx.x < n_dep ? D.depA[(int64_t)slot * D.max_colony + base + threadIdx.x] : 0.f;
     __syncthreads();
     const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
@@ -1177,13 +1225,15 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
     const uint32_t ver = c->best_ver;
     const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
-    for (int32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    for (int32_t i = 1 + bx * blockDim.x + threadIdx.x; i < len; i += nbx * blockDim.x) {
         int32_t w = path[i];
         int32_t v = path[i - 1] & WA_ID_MASK;
+        const bool v_best = mark[v] == ver;
+        if (skip_best_src && v_best) continue;
         int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
         unsigned long long m = mask[e];
         if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
-        bool onbest = mark[v] == ver && mark[w & WA_ID_MASK] == ver;  // :209
+        bool onbest = v_best && mark[w & WA_ID_MASK] == ver;          // :209
         const float bonus = (float)onbest * lambda * Q / bestL;       // second term of :211, the same for every rank
         float p = pher[e];
         while (m) {
@@ -1194,4 +1244,10 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
         pher[e] = p;
         mask[e] = 0;
     }
+}
+
+__global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
+{
+    __shared__ float s_dep_[64];
+    wa_apply_body(D, blockIdx.z, base, blockIdx.y, blockIdx.x, gridDim.x, false, s_dep_);
 }

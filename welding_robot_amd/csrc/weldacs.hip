@@ -46,7 +46,7 @@ struct wa_acs {
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     int cur_buf;
     WaRun R;
-    bool begun, overlap_walk, overlap_rank, fuse, inplace;
+    bool begun, overlap_walk, overlap_rank, fuse, inplace, fuse_table;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
@@ -388,6 +388,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->overlap_walk = env_int("WA_OVERLAP_WALK", 0) != 0;
     s->overlap_rank = env_int("WA_OVERLAP_RANK", 0) != 0;
     s->fuse = env_int("WA_FUSE", 1) != 0;
+    s->fuse_table = env_int("WA_FUSE_TABLE", 1) != 0;
     s->inplace = env_int("WA_EVAP_INPLACE", 0) != 0 && !s->overlap_walk;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
@@ -653,8 +654,12 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             if (!s->inplace) s->cur_buf ^= 1;
             s->D.pher = dst;
             e = prof_open(s, WA_K_DEPOSIT, sampled);
-            k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
-            if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+            if (s->D.rtab && s->fuse_table) {
+                k_apply_table<<<dim3(WA_TABLE_BLOCKS + 512, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+            } else {
+                k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
+                if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+            }
             prof_close(s, e);
             s->gens_enqueued++;
             continue;
