@@ -25,6 +25,9 @@
 //             seed= iters= predict= [driven=0|1] [fixed=N] [dumppher=1]
 //   pairs     (stl= p= wall= | gridin=) pts=FILE predict= seed= graph=FILE [gtsp=1]
 //   gtsp      graph=FILE seed=
+//   bspline   deg= ci= cf= n= seed= tf= [fill=HEX] [t0= dt= count=]   BS_Basic<float,3,deg,ci,cf>
+//   (pairs ... gtsp=1 smooth=1 additionally runs main.cpp:287-352's two smoothing passes on the
+//    stitched path with the clock()-paced sampling replaced by fixed times)
 // every command takes out=FILE (WAF) and prints one JSON line with timings on stderr.
 #include <dlfcn.h>
 #include <sys/time.h>
@@ -34,6 +37,7 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -53,9 +57,28 @@ extern "C" int rand(void)
     return real();
 }
 
+// BS_Basic reads heap cells it never wrote (c_mat[idx][CL+1] when CL+1 > DEGREE,
+// BSplineBasic.h:414-431).  While g_fill_on is set every new[] block is pre-filled with a
+// known 32-bit pattern, which turns that read into a defined input of the run.
+static bool g_fill_on = false;
+static uint32_t g_fill_bits = 0;
+void *operator new[](std::size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    if (g_fill_on) {
+        uint32_t *w = (uint32_t *)p;
+        for (size_t i = 0; i < n / 4; i++) w[i] = g_fill_bits;
+    }
+    return p;
+}
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete[](void *p, std::size_t) noexcept { free(p); }
+
 #include "core/ACSRank_3D.hpp"
 #include "core/read_STL.hpp"
 #include "core/ACS_GTSP.hpp"
+#include "core/BSplineBasic.h"
 
 static double now_s()
 {
@@ -392,6 +415,7 @@ static void dump_gtsp(Waf &w, ACS_GTSP &g)
     w.one_f64("gtsp_pher0", g.pheromone_0);
 }
 
+static void smooth_like_main(Waf &w, ACS_GTSP &g, uint32_t fill_bits);
 static int cmd_pairs(const Args &a, Waf &w)
 {
     // The unmodified main.cpp:279-283 sequence.  srand(time(0)) inside initFromGridMap
@@ -437,6 +461,7 @@ static int cmd_pairs(const Args &a, Waf &w)
         w.f32("g_path_y", g.g_path_y);
         w.f32("g_path_z", g.g_path_z);
         w.one_i64("segments", g.path_segment_nums());
+        if (getl(a, "smooth", 0)) smooth_like_main(w, g, (uint32_t)strtoul(gets(a, "fill", "0").c_str(), nullptr, 16));
     }
     w.one_i64("next_rand", rand());
     fprintf(stderr, "{\"cmd\":\"pairs\",\"t_pairs\":%.6f,\"t_gtsp\":%.6f}\n", t_pairs, t_gtsp);
@@ -469,9 +494,148 @@ static int cmd_gtsp(const Args &a, Waf &w)
     return 0;
 }
 
+// ---------------------------------------------------------------- BS_Basic
+static uint64_t sm64(uint64_t &st)
+{
+    uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int DEG, int CI, int CF>
+static void run_spline(Waf &w, const char *tag, const std::vector<float> &init, const std::vector<float> &fin,
+                       const std::vector<float> &mid, int stride, float tf, const std::vector<float> &us,
+                       float t0, float dt, int count)
+{
+    int n = (int)(mid.size() / stride);
+    std::vector<float *> rows(n);
+    std::vector<float> midc(mid);
+    for (int i = 0; i < n; i++) rows[i] = &midc[(size_t)i * stride];
+    std::vector<float> ic(init), fc(fin);
+    BS_Basic<float, 3, DEG, CI, CF> sp(n);
+    sp.SetParam(ic.data(), fc.data(), rows.data(), tf);
+    std::string t(tag);
+    w.f32((t + "knots").c_str(), std::vector<float>(sp.Knots_, sp.Knots_ + sp.NumKnots_));
+    std::vector<float> cps;
+    for (int i = 0; i < sp.NumCPs_; i++) cps.insert(cps.end(), sp.CPoints_[i], sp.CPoints_[i] + 3);
+    w.f32((t + "cps").c_str(), cps);
+    // explicit times: position and every derivative level up to DEG (+1 to exercise d > DEGREE)
+    for (int d = 0; d <= DEG + 1; d++) {
+        std::vector<float> out(us.size() * 3, -777.0f);
+        std::vector<uint8_t> ok(us.size());
+        for (size_t i = 0; i < us.size(); i++)
+            ok[i] = d == 0 ? sp.getCurvePoint(us[i], &out[i * 3]) : sp.getCurveDerPoint(us[i], d, &out[i * 3]);
+        char nm[64];
+        snprintf(nm, sizeof nm, "%sder%d", tag, d);
+        w.f32(nm, out);
+        snprintf(nm, sizeof nm, "%sok%d", tag, d);
+        w.u8(nm, ok);
+    }
+    // fixed-rate sampling u_i = t0 + i*dt
+    std::vector<float> smp((size_t)count * 3, -777.0f);
+    for (int i = 0; i < count; i++) {
+        float u = t0 + (float)i * dt;
+        sp.getCurvePoint(u, &smp[(size_t)i * 3]);
+    }
+    w.f32((t + "samples").c_str(), smp);
+}
+
+#define SPLINE_CASES(X) X(0,0,0) X(1,0,0) X(1,1,1) X(2,0,0) X(2,1,1) X(2,2,2) X(2,2,1) X(3,0,0) X(3,1,1) \
+                        X(3,2,2) X(3,3,3) X(3,1,2) X(4,3,3) X(5,2,2) X(5,4,4)
+
+static int cmd_bspline(const Args &a, Waf &w)
+{
+    int deg = (int)getl(a, "deg", 0), ci = (int)getl(a, "ci", 0), cf = (int)getl(a, "cf", 0);
+    int n = (int)getl(a, "n", 10);
+    float tf = getf(a, "tf", 150.0f);
+    uint64_t st = (uint64_t)getl(a, "seed", 1);
+    g_fill_bits = (uint32_t)strtoul(gets(a, "fill", "0").c_str(), nullptr, 16);
+    float t0 = getf(a, "t0", 0.0f), dt = getf(a, "dt", 1.0f);
+    int count = (int)getl(a, "count", 32);
+    const int stride = 3 + (int)getl(a, "pad", 0);      // main.cpp:325 passes rows of 9 floats
+    // inputs: a bounded random walk (middle points), end states with velocity/acceleration rows
+    std::vector<float> mid((size_t)n * stride), init(3 * 8), fin(3 * 8);
+    float p[3] = {0.25f, -1.5f, 3.0f};
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            p[k] += ((float)(sm64(st) >> 40) / 16777216.0f - 0.5f) * 0.125f;
+            mid[(size_t)i * stride + k] = p[k];
+        }
+        for (int k = 3; k < stride; k++) mid[(size_t)i * stride + k] = 0.05f;
+    }
+    for (int k = 0; k < 24; k++) {
+        init[k] = ((float)(sm64(st) >> 40) / 16777216.0f - 0.5f) * (k < 3 ? 4.0f : 0.02f);
+        fin[k] = ((float)(sm64(st) >> 40) / 16777216.0f - 0.5f) * (k < 3 ? 4.0f : 0.02f);
+    }
+    // times: out of range, the ends, near-end (SP_IS_EQUAL window), every knot, random interior
+    std::vector<float> us = {-5.0f, 0.0f, tf, tf + 7.0f, tf - 1e-6f * tf, tf - 5e-6f, tf - 2e-5f, tf * 0.5f,
+                             nextafterf(tf, 0.0f), nextafterf(0.0f, 1.0f), 1e-30f};
+    int nk = deg + n + 2 + ci + cf + 1, nmid = nk - 2 * deg - 2;
+    float step = tf / (float)(nmid + 1), kk = 0.0f;
+    for (int i = 0; i < nmid && i < 64; i++) { kk += step; us.push_back(kk); us.push_back(nextafterf(kk, 0.0f)); }
+    for (int i = 0; i < 64; i++) us.push_back((float)(sm64(st) >> 40) / 16777216.0f * tf);
+    w.f32("init", init); w.f32("fin", fin); w.f32("middle", mid); w.f32("u", us);
+    w.one_f32("tf", tf); w.one_f32("t0", t0); w.one_f32("dt", dt);
+    w.one_i64("count", count); w.one_i64("stride", stride); w.one_i64("n_middle", n);
+    w.one_i64("deg", deg); w.one_i64("ci", ci); w.one_i64("cf", cf); w.one_i64("fill_bits", g_fill_bits);
+    g_fill_on = true;
+    bool done = false;
+#define X(D, I, F) if (deg == D && ci == I && cf == F) { run_spline<D, I, F>(w, "", init, fin, mid, stride, tf, us, t0, dt, count); done = true; }
+    SPLINE_CASES(X)
+#undef X
+    g_fill_on = false;
+    if (!done) { fprintf(stderr, "bspline: combination not instantiated\n"); return 2; }
+    fprintf(stderr, "{\"cmd\":\"bspline\",\"deg\":%d,\"ci\":%d,\"cf\":%d,\"n\":%d}\n", deg, ci, cf, n);
+    return 0;
+}
+
+// main.cpp:287-352 with the two clock()-paced loops replaced by fixed sample times
+// (pass 1: 10, 20, ... 160 "ticks" of a 150-tick spline; pass 2: 50, 100, ... 6050 of 6000).
+static void smooth_like_main(Waf &w, ACS_GTSP &g, uint32_t fill_bits)
+{
+    int pt_num = (int)g.g_path_x.size();
+    if (pt_num < 2) return;
+    g_fill_bits = fill_bits;
+    g_fill_on = true;
+    std::vector<float> init = {g.g_path_x[0], g.g_path_y[0], g.g_path_z[0]};
+    std::vector<float> fin = {g.g_path_x[pt_num - 1], g.g_path_y[pt_num - 1], g.g_path_z[pt_num - 1]};
+    std::vector<float> mid((size_t)pt_num * 3);
+    for (int i = 0; i < pt_num; i++) {
+        mid[(size_t)i * 3 + 0] = g.g_path_x[i];
+        mid[(size_t)i * 3 + 1] = g.g_path_y[i];
+        mid[(size_t)i * 3 + 2] = g.g_path_z[i];
+    }
+    std::vector<float> none;
+    run_spline<0, 0, 0>(w, "s1_", init, fin, mid, 3, 150.0f, none, 10.0f, 10.0f, 16);
+    // second pass: reread pass-1 samples through the reference class (as main.cpp does)
+    std::vector<float *> rows(pt_num);
+    for (int i = 0; i < pt_num; i++) rows[i] = &mid[(size_t)i * 3];
+    BS_Basic<float, 3, 0, 0, 0> c1(pt_num);
+    c1.SetParam(init.data(), fin.data(), rows.data(), 150.0f);
+    std::vector<float> sx, sy, sz;
+    for (int i = 0; i < 16; i++) {
+        float r[3], u = 10.0f + (float)i * 10.0f;
+        c1.getCurvePoint(u, r);
+        sx.push_back(r[0]); sy.push_back(r[1]); sz.push_back(r[2]);
+    }
+    const float constrain = 0.05f;
+    int n2 = (int)sy.size();
+    // main.cpp:323 indexes g_path with the *new* pt_num; keep that
+    std::vector<float> i2 = {g.g_path_x[0], g.g_path_y[0], g.g_path_z[0], 0, 0, 0, 0, 0, 0};
+    int last = n2 - 1 < pt_num ? n2 - 1 : pt_num - 1;
+    std::vector<float> f2 = {g.g_path_x[last], g.g_path_y[last], g.g_path_z[last], 0, 0, 0, 0, 0, 0};
+    std::vector<float> m2((size_t)n2 * 9, constrain);
+    for (int i = 0; i < n2; i++) { m2[(size_t)i * 9] = sx[i]; m2[(size_t)i * 9 + 1] = sy[i]; m2[(size_t)i * 9 + 2] = sz[i]; }
+    w.f32("s2_init", i2); w.f32("s2_fin", f2); w.f32("s2_middle", m2);
+    run_spline<2, 2, 2>(w, "s2_", i2, f2, m2, 9, 6000.0f, none, 50.0f, 50.0f, 121);
+    g_fill_on = false;
+    w.one_i64("smooth_fill_bits", fill_bits);
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness <rand|sort|voxelize|acs|pairs|gtsp> key=value...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness <rand|sort|voxelize|acs|pairs|gtsp|bspline> key=value...\n"); return 2; }
     Args a = parse(argc, argv);
     if (!has(a, "out")) { fprintf(stderr, "out=FILE required\n"); return 2; }
     // the reference narrates every generation / distance on stdout: silence it
@@ -484,6 +648,7 @@ int main(int argc, char **argv)
     if (c == "acs") return cmd_acs(a, w);
     if (c == "pairs") return cmd_pairs(a, w);
     if (c == "gtsp") return cmd_gtsp(a, w);
+    if (c == "bspline") return cmd_bspline(a, w);
     fprintf(stderr, "unknown command %s\n", argv[1]);
     return 2;
 }

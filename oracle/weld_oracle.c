@@ -735,3 +735,260 @@ int32_t wo_gtsp_solve(const double *dist, int32_t n, int32_t cnt, const wo_gtsp_
     free(pher); free(heur); free(info); free(inJ); free(r); free(cntJ); free(tours); free(best);
     return it;
 }
+
+/* =====================================================================================
+ * BS_Basic<float, DIM, DEGREE, CI, CF>  (core/BSplineBasic.h) -- trajectory smoothing that
+ * main.cpp:287-352 applies to the stitched path.  Template arguments are run-time here.
+ * ===================================================================================== */
+#define BS_W (WO_BS_MAX_DEGREE + 1)
+
+int wo_bspline_init(wo_bspline *b, int32_t dim, int32_t degree, int32_t ci, int32_t cf,
+                    int64_t n_middle, float uninit)
+{
+    memset(b, 0, sizeof *b);
+    /* ci/cf > DEGREE would index _ndu[DEGREE-k+1] with a negative row (:279-281): not restated */
+    if (dim < 1 || dim > WO_BS_MAX_DIM || degree < 0 || degree > WO_BS_MAX_DEGREE || ci < 0 ||
+        cf < 0 || ci > degree || cf > degree || n_middle < 0)
+        return -1;
+    b->dim = dim; b->degree = degree; b->ci = ci; b->cf = cf; b->n_middle = n_middle;
+    b->n_knots = degree + n_middle + 2 + ci + cf + 1;                         /* :38-39 */
+    b->n_cps = n_middle + 2 + ci + cf;                                        /* :40    */
+    if (b->n_knots < 2 * (degree + 1)) return -1;                             /* :53-55 "Invalid setup" */
+    b->knots = (float *)calloc((size_t)b->n_knots, sizeof(float));            /* :44 zeroed */
+    b->cps = (float *)calloc((size_t)(b->n_cps * dim), sizeof(float));        /* :47-51 zeroed */
+    b->uninit = uninit;
+    return (b->knots && b->cps) ? 0 : -1;
+}
+
+void wo_bspline_free(wo_bspline *b)
+{
+    free(b->knots); free(b->cps);
+    b->knots = NULL; b->cps = NULL;
+}
+
+/* _findSpan :358-385 */
+static int bs_find_span(const wo_bspline *b, float u, int64_t *ret)
+{
+    const float *K = b->knots;
+    int64_t nk = b->n_knots;
+    if (u < K[0] || K[nk - 1] < u) return 0;
+    float d = u - K[nk - 1];
+    if ((double)(d * d) < 1.e-10) {            /* SP_IS_EQUAL :8: fp32 product against a double literal */
+        for (int64_t i = nk - 2; i > -1; --i)
+            if (K[i] < u && u <= K[i + 1]) { *ret = i; return 1; }
+        return 0;
+    }
+    int64_t low = 0, high = nk - 1, mid = (low + high) >> 1;
+    int guard = 0;
+    while (u < K[mid] || u >= K[mid + 1]) {
+        if (u < K[mid]) high = mid; else low = mid;
+        mid = (low + high) >> 1;
+        if (++guard > 200) return 0;           /* the reference would spin forever (non-monotone knots) */
+    }
+    *ret = mid;
+    return 1;
+}
+
+/* _BasisFuns :330-353, with _Left/_Right :354-356 */
+static void bs_basis_funs(const wo_bspline *b, float *N, int64_t span, float u)
+{
+    const float *K = b->knots;
+    float left = 0.0f, right = 0.0f, saved = 0.0f, temp = 0.0f;
+    N[0] = 1.0f;
+    for (int j = 1; j <= b->degree; ++j) {
+        saved = 0.0f;
+        for (int r = 0; r < j; ++r) {
+            left = u - K[span + 1 - (j - r)];
+            right = K[span + (r + 1)] - u;
+            if ((right + left) != 0) temp = N[r] / (right + left);   /* temp survives a zero sum */
+            N[r] = saved + right * temp;
+            saved = left * temp;
+        }
+        N[j] = saved;
+    }
+}
+
+/* _BasisFunsDers(ders, span, u, n) :237-323 */
+static void bs_basis_ders(const wo_bspline *b, float ders[][BS_W + 2], int64_t span, float u, int n)
+{
+    const float *K = b->knots;
+    const int D = b->degree;
+    float ndu[BS_W][BS_W], a[2][BS_W];
+    float saved = 0.0f, left = 0.0f, right = 0.0f, temp = 0.0f, d = 0.0f;
+    for (int i = 0; i < BS_W; i++)
+        for (int j = 0; j < BS_W; j++) ndu[i][j] = b->uninit;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < BS_W; j++) a[i][j] = b->uninit;
+    ndu[0][0] = 1.0f;
+    for (int j = 1; j <= D; ++j) {
+        saved = 0.0f;
+        for (int r = 0; r < j; ++r) {
+            left = u - K[span + 1 - (j - r)];
+            right = K[span + (r + 1)] - u;
+            ndu[j][r] = right + left;
+            temp = ndu[r][j - 1] / ndu[j][r];
+            ndu[r][j] = saved + right * temp;
+            saved = left * temp;
+        }
+        ndu[j][j] = saved;
+    }
+    for (int j = 0; j <= D; ++j) ders[0][j] = ndu[j][D];
+    for (int r = 0; r <= D; ++r) {
+        int s1 = 0, s2 = 1;
+        a[0][0] = 1.0f;
+        for (int k = 1; k <= n; ++k) {
+            d = 0.0f;
+            int rk = r - k, pk = D - k, j1, j2;
+            if (r >= k) {
+                a[s2][0] = a[s1][0] / ndu[pk + 1][rk];
+                d = a[s2][0] * ndu[rk][pk];
+            }
+            j1 = (rk >= -1) ? 1 : -rk;
+            j2 = (r - 1 <= pk) ? k - 1 : D - r;
+            for (int j = j1; j <= j2; ++j) {
+                a[s2][j] = (a[s1][j] - a[s1][j - 1]) / ndu[pk + 1][rk + j];
+                d += a[s2][j] * ndu[rk + j][pk];
+            }
+            if (r <= pk) {
+                a[s2][k] = -a[s1][k - 1] / ndu[pk + 1][r];
+                d += a[s2][k] * ndu[r][pk];
+            }
+            ders[k][r] = d;
+            int t = s1; s1 = s2; s2 = t;
+        }
+    }
+    int r = D;
+    for (int k = 1; k <= n; ++k) {
+        for (int j = 0; j <= D; ++j) ders[k][j] *= (float)r;
+        r *= (D - k);
+    }
+}
+
+/* _BasisFunsDers(ders, u, n) :227-235: nothing is written when the span search fails */
+static void bs_basis_ders_at(const wo_bspline *b, float ders[][BS_W + 2], float u, int n)
+{
+    int64_t span;
+    if (!bs_find_span(b, u, &span)) return;
+    bs_basis_ders(b, ders, span, u, n);
+}
+
+void wo_bspline_set_param(wo_bspline *b, const float *init, const float *fin, const float *middle,
+                          int64_t stride, float fin_time)
+{
+    const int D = b->degree, dim = b->dim;
+    float *K = b->knots, *C = b->cps;
+    /* _CalcKnot :150-171 */
+    {
+        int64_t i = 0;
+        int64_t nmid = b->n_knots - 2 * D - 2;
+        float step = fin_time / (float)(nmid + 1);
+        for (int j = 0; j < D + 1; ++j) K[i++] = 0.0f;
+        for (int64_t j = 0; j < nmid; ++j) { K[i] = K[i - 1] + step; ++i; }
+        for (int j = 0; j < D + 1; ++j) K[i++] = fin_time;
+    }
+    /* _CalcConstrainedCPoints :387-447 */
+    for (int m = 0; m < dim; ++m) {
+        C[m] = init[m];
+        C[(b->n_cps - 1) * dim + m] = fin[m];
+    }
+    float mat[BS_W][BS_W + 2];
+    for (int i = 0; i < BS_W; i++)
+        for (int j = 0; j < BS_W + 2; j++) mat[i][j] = b->uninit;
+    bs_basis_ders_at(b, mat, 0.0f, b->ci);
+    for (int j = 1; j < b->ci + 1; ++j)
+        for (int k = 0; k < dim; ++k) {
+            float v = init[j * dim + k];
+            for (int h = j; h > 0; --h) v -= mat[j][h - 1] * C[(h - 1) * dim + k];
+            C[j * dim + k] = v / mat[j][j];
+        }
+    for (int i = 0; i < BS_W; i++)
+        for (int j = 0; j < BS_W + 2; j++) mat[i][j] = b->uninit;
+    bs_basis_ders_at(b, mat, fin_time, b->cf);
+    {
+        int idx = 1;
+        for (int64_t j = b->n_cps - 2; j > b->n_cps - 2 - b->cf; --j) {
+            for (int k = 0; k < dim; ++k) {
+                float v = fin[idx * dim + k];
+                for (int h = idx; h > 0; --h)
+                    v -= mat[idx][b->cf + 2 - h] * C[(b->n_cps - h) * dim + k];   /* column cf+1 is never written when cf+1 > DEGREE */
+                C[j * dim + k] = v / mat[idx][b->cf + 1 - idx];
+            }
+            ++idx;
+        }
+    }
+    /* _CalcCPoints :458-464 */
+    for (int64_t i = 0; i < b->n_middle; ++i)
+        for (int m = 0; m < dim; ++m) C[(b->ci + 1 + i) * dim + m] = middle[i * stride + m];
+}
+
+static int bs_span_in_range(const wo_bspline *b, int64_t span)
+{
+    return span - b->degree >= 0 && span < b->n_cps && span + b->degree < b->n_knots;
+}
+
+int wo_bspline_point(const wo_bspline *b, float u, float *ret)
+{
+    const float *K = b->knots;
+    int64_t span;
+    if (u < K[0]) u = K[0];
+    else if (u > K[b->n_knots - 1]) u = K[b->n_knots - 1];
+    if (!bs_find_span(b, u, &span)) return 0;
+    if (!bs_span_in_range(b, span)) return 0;      /* reference: out-of-bounds read */
+    float N[BS_W];
+    bs_basis_funs(b, N, span, u);
+    for (int j = 0; j < b->dim; ++j) {
+        float c = 0.0f;
+        for (int i = 0; i <= b->degree; ++i) c += N[i] * b->cps[(span - b->degree + i) * b->dim + j];
+        ret[j] = c;
+    }
+    return 1;
+}
+
+int wo_bspline_der(const wo_bspline *b, float u, int32_t d, float *ret)
+{
+    const float *K = b->knots;
+    int64_t span;
+    if (d > b->degree || d < 0) return 0;          /* :123 `return 0.0` == false */
+    if (u < K[0]) u = K[0];
+    else if (u > K[b->n_knots - 1]) u = K[b->n_knots - 1];
+    if (!bs_find_span(b, u, &span)) return 0;      /* _CurveDerivsAlg1V :173-203 */
+    if (!bs_span_in_range(b, span)) return 0;
+    float nders[BS_W][BS_W + 2];
+    bs_basis_ders(b, nders, span, u, d);
+    for (int m = 0; m < b->dim; ++m) {
+        float c = 0.0f;
+        for (int j = 0; j <= b->degree; ++j) c += nders[d][j] * b->cps[(span - b->degree + j) * b->dim + m];
+        ret[m] = c;
+    }
+    return 1;
+}
+
+void wo_bspline_sample(const wo_bspline *b, float t0, float dt, int64_t count, int32_t der, float *out,
+                       uint8_t *ok)
+{
+    for (int64_t i = 0; i < count; ++i) {
+        float u = t0 + (float)i * dt;
+        int r = der == 0 ? wo_bspline_point(b, u, out + i * b->dim) : wo_bspline_der(b, u, der, out + i * b->dim);
+        if (ok) ok[i] = (uint8_t)r;
+    }
+}
+
+/* ACS_GTSP::read_all_segments (ACS_GTSP.hpp:286-298): segment after segment, node after node;
+ * node id -> (x, y, z) index -> axis-table coordinates (model_grid_map.hpp:204-215) */
+void wo_stitch_segments(const int64_t *seg_ids, const int64_t *seg_off, int32_t n_seg, const uint8_t *reverse,
+                        int32_t nx, int32_t ny, const float *cx, const float *cy, const float *cz,
+                        float *out_xyz)
+{
+    int64_t o = 0;
+    for (int32_t s = 0; s < n_seg; ++s) {
+        int64_t a = seg_off[s], e = seg_off[s + 1];
+        for (int64_t j = 0; j < e - a; ++j) {
+            int64_t id = (reverse && reverse[s]) ? seg_ids[e - 1 - j] : seg_ids[a + j];
+            int64_t x = id % nx, y = (id / nx) % ny, z = id / ((int64_t)nx * ny);
+            out_xyz[o * 3 + 0] = cx[x];
+            out_xyz[o * 3 + 1] = cy[y];
+            out_xyz[o * 3 + 2] = cz[z];
+            ++o;
+        }
+    }
+}

@@ -44,8 +44,53 @@ ACS_KEYS = ["dims", "precision", "start_id", "end_id", "points_ok", "best_L", "b
             "tr_colony", "tr_finite", "tr_steps", "tr_bestL", "tr_iterbestL", "tr_lambda", "tr_Q"]
 
 
+BSPLINE_CASES = [  # (tag, deg, ci, cf, n, tf, fill, pad, t0, dt, count)
+    ("d0_main1", 0, 0, 0, 62, "150", "0", 0, "10", "10", 16),            # main.cpp:299-300 shape
+    ("d2_main2", 2, 2, 2, 16, "6000", "0", 6, "50", "50", 121),          # main.cpp:337-338 shape
+    ("d2_main2_fill1", 2, 2, 2, 16, "6000", "3f800000", 6, "50", "50", 121),
+    ("d2_main2_fillnan", 2, 2, 2, 5, "77.7", "7fc00000", 0, "-3", "1.5", 60),
+    ("d1", 1, 0, 0, 9, "1", "0", 0, "0", "0.03125", 40),
+    ("d1c", 1, 1, 1, 33, "12.5", "bf000000", 0, "-1", "0.25", 60),
+    ("d2", 2, 1, 1, 40, "2.5", "0", 0, "0", "0.05", 55),
+    ("d3", 3, 2, 2, 25, "150", "0", 0, "-3", "3", 60),                   # DEGREE = CL+1: the well-defined use
+    ("d3_asym", 3, 1, 2, 7, "9", "3f800000", 0, "0", "0.2", 50),
+    ("d3_full", 3, 3, 3, 300, "6000", "0", 0, "0", "13.7", 450),
+    ("d4", 4, 3, 3, 12, "33", "0", 0, "0", "0.5", 70),
+    ("d5", 5, 2, 2, 1, "1", "0", 0, "0", "0.02", 55),
+    ("d5_full", 5, 4, 4, 50, "100", "0", 0, "-2", "1", 110),
+]
+
+
+def gen_bspline():
+    out = {}
+    for tag, deg, ci, cf, n, tf, fill, pad, t0, dt, count in BSPLINE_CASES:
+        g = O.run_ref("bspline", TMP + "/bs.waf", deg=deg, ci=ci, cf=cf, n=n, seed=1000 + n, tf=tf, fill=fill,
+                      pad=pad, t0=t0, dt=dt, count=count)
+        for k, v in g.items():
+            out["%s/%s" % (tag, k)] = v
+    waf.save(HERE + "/bspline_cases.waf", out)
+    print("bspline cases", len(BSPLINE_CASES), os.path.getsize(HERE + "/bspline_cases.waf"), "bytes")
+
+
+def gen_smooth():
+    """main.cpp:273-352 end to end on cubic: pairs -> GTSP -> stitched path -> two smoothing passes
+    (fixed sample times instead of clock()).  Same seed/arguments as pairs_cubic.waf."""
+    pts = HERE + "/cubic_weld_points.in"
+    for fill in ("0", "3f800000"):
+        pr = O.run_ref("pairs", TMP + "/ps.waf", stl=HERE + "/cubic.stl", p="0.0219", wall=8, pts=pts, predict="0.5",
+                       seed=4321, graph=TMP + "/graph_s.in", gtsp=1, smooth=1, fill=fill)
+        keys = ["g_path_x", "g_path_y", "g_path_z", "tour_edges", "segments", "pair_len", "pair_paths_upper",
+                "smooth_fill_bits"] + [k for k in pr if k.startswith("s1_") or k.startswith("s2_")]
+        waf.save(HERE + "/smooth_cubic_fill%s.waf" % fill, keep(pr, keys))
+        print("smooth", fill, len(pr["g_path_x"]), pr["s2_samples"].reshape(-1, 3)[[0, 60, -1]])
+
+
 def main():
     assert O.have_ref(), "build oracle/_ref first: make -C oracle"
+    if len(sys.argv) > 1 and sys.argv[1] == "bspline":      # regenerate only the trajectory fixtures
+        gen_bspline()
+        gen_smooth()
+        return
     for f in ("cubic.stl", "simplified_piece.stl"):
         shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))
         os.chmod(os.path.join(HERE, f), 0o644)
@@ -141,6 +186,10 @@ def main():
     g64.pop("t_gtsp", None)
     waf.save(HERE + "/gtsp_n64.waf", g64)
     print("gtsp64", g64["tour_L"], g64["gtsp_iters"])
+
+    # ---- BS_Basic trajectory smoothing ------------------------------------------
+    gen_bspline()
+    gen_smooth()
 
 
 if __name__ == "__main__":

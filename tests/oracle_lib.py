@@ -26,6 +26,12 @@ class AcsParams(C.Structure):
                 ("stream", C.c_uint32)]
 
 
+class BsplineStruct(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("degree", C.c_int32), ("ci", C.c_int32), ("cf", C.c_int32),
+                ("n_middle", C.c_int64), ("n_knots", C.c_int64), ("n_cps", C.c_int64),
+                ("knots", C.POINTER(C.c_float)), ("cps", C.POINTER(C.c_float)), ("uninit", C.c_float)]
+
+
 class GtspParams(C.Structure):
     _fields_ = [("rng_mode", C.c_int32), ("seed", C.c_uint64), ("stream", C.c_uint32),
                 ("max_iterations", C.c_int32)]
@@ -86,6 +92,15 @@ def lib():
         L.wo_gtsp_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GtspParams), C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.wo_std_sort_perm.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        BP = C.POINTER(BsplineStruct)
+        L.wo_bspline_init.argtypes = [BP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_float]
+        L.wo_bspline_free.argtypes = [BP]
+        L.wo_bspline_set_param.argtypes = [BP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
+        L.wo_bspline_point.argtypes = [BP, C.c_float, C.c_void_p]
+        L.wo_bspline_der.argtypes = [BP, C.c_float, C.c_int32, C.c_void_p]
+        L.wo_bspline_sample.argtypes = [BP, C.c_float, C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.wo_stitch_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wo_stable_rank_perm.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
@@ -259,6 +274,69 @@ def gtsp_solve(dist, cnt=None, mode=REF, rng=None, seed=0, stream=0, max_iterati
     it = lib().wo_gtsp_solve(dist.ctypes.data, n, cnt, C.byref(p), C.byref(rng) if rng is not None else None,
                              edges.ctypes.data, C.byref(L), pher.ctypes.data if want_pher else None)
     return dict(iters=it, edges=edges.reshape(n, 2), L=L.value, pher=pher)
+
+
+class Bspline:
+    """BS_Basic<float, dim, degree, ci, cf> restated (BSplineBasic.h); `uninit_bits` is the 32-bit
+    pattern of the heap cells the reference reads without writing."""
+
+    def __init__(self, dim, degree, ci, cf, n_middle, uninit_bits=0):
+        self.s = BsplineStruct()
+        un = np.array([uninit_bits], np.uint32).view(np.float32)[0]
+        if lib().wo_bspline_init(C.byref(self.s), dim, degree, ci, cf, n_middle, C.c_float(un)) != 0:
+            raise ValueError("invalid BS_Basic arguments")
+        self.dim, self.degree = dim, degree
+
+    def __del__(self):
+        if getattr(self, "s", None) is not None:
+            lib().wo_bspline_free(C.byref(self.s))
+            self.s = None
+
+    def set_param(self, init, fin, middle, fin_time):
+        init = np.ascontiguousarray(init, np.float32)
+        fin = np.ascontiguousarray(fin, np.float32)
+        middle = np.ascontiguousarray(middle, np.float32)
+        middle = middle.reshape(self.s.n_middle, -1) if middle.size else np.zeros((0, self.dim), np.float32)
+        lib().wo_bspline_set_param(C.byref(self.s), init.ctypes.data, fin.ctypes.data, middle.ctypes.data,
+                                   middle.shape[1], C.c_float(fin_time))
+
+    @property
+    def knots(self):
+        return np.ctypeslib.as_array(self.s.knots, (self.s.n_knots,)).copy()
+
+    @property
+    def cps(self):
+        return np.ctypeslib.as_array(self.s.cps, (self.s.n_cps * self.dim,)).copy().reshape(-1, self.dim)
+
+    def eval(self, us, der=0, prefill=-777.0):
+        us = np.ascontiguousarray(us, np.float32)
+        out = np.full((len(us), self.dim), prefill, np.float32)
+        ok = np.zeros(len(us), np.uint8)
+        for i, u in enumerate(us):
+            row = out[i]
+            ok[i] = (lib().wo_bspline_point(C.byref(self.s), C.c_float(u), row.ctypes.data) if der == 0 else
+                     lib().wo_bspline_der(C.byref(self.s), C.c_float(u), der, row.ctypes.data))
+        return out, ok
+
+    def sample(self, t0, dt, count, der=0, prefill=-777.0):
+        out = np.full((count, self.dim), prefill, np.float32)
+        ok = np.zeros(count, np.uint8)
+        lib().wo_bspline_sample(C.byref(self.s), C.c_float(t0), C.c_float(dt), count, der, out.ctypes.data,
+                                ok.ctypes.data)
+        return out, ok
+
+
+def stitch_segments(seg_ids, seg_off, reverse, nx, ny, cx, cy, cz):
+    seg_ids = np.ascontiguousarray(seg_ids, np.int64)
+    seg_off = np.ascontiguousarray(seg_off, np.int64)
+    rev = np.ascontiguousarray(reverse, np.uint8) if reverse is not None else None
+    out = np.zeros((len(seg_ids), 3), np.float32)
+    lib().wo_stitch_segments(seg_ids.ctypes.data, seg_off.ctypes.data, len(seg_off) - 1,
+                             rev.ctypes.data if rev is not None else None, nx, ny,
+                             np.ascontiguousarray(cx, np.float32).ctypes.data,
+                             np.ascontiguousarray(cy, np.float32).ctypes.data,
+                             np.ascontiguousarray(cz, np.float32).ctypes.data, out.ctypes.data)
+    return out
 
 
 def pher_hash(pher):
