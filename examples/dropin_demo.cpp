@@ -1,6 +1,7 @@
-// examples/dropin_demo.cpp -- the planning sequence of the reference's main.cpp:273-283, compiled
+// examples/dropin_demo.cpp -- the planning sequence of the reference's main.cpp:273-352, compiled
 // against the drop-in headers (welding_robot_amd/include/core) and libweldacs.so instead of the
-// reference's header-only classes.  The five calls in the middle are verbatim main.cpp.
+// reference's header-only classes.  The five planning calls and the two smoothing passes are verbatim
+// main.cpp, except that the clock()-paced sampling loops (:302-316, :341-351) use fixed times.
 //
 //   g++ -std=c++14 -Iinclude -Iwelding_robot_amd/include examples/dropin_demo.cpp
 //       -Lwelding_robot_amd/lib -lweldacs -Wl,-rpath,$PWD/welding_robot_amd/lib -o dropin_demo
@@ -12,6 +13,7 @@
 #include "core/ACSRank_3D.hpp"
 #include "core/read_STL.hpp"
 #include "core/ACS_GTSP.hpp"
+#include "core/BSplineBasic.h"
 
 STLReader model;
 ACS_Rank SearchPath;
@@ -52,6 +54,51 @@ int main(int argc, char **argv)
     fprintf(out, "gpath %d\n", (int)GlobalRoute.g_path_x.size());
     for (size_t i = 0; i < GlobalRoute.g_path_x.size(); i++)
         fprintf(out, "%.9g %.9g %.9g\n", (double)GlobalRoute.g_path_x[i], (double)GlobalRoute.g_path_y[i], (double)GlobalRoute.g_path_z[i]);
+
+    // ---- main.cpp:287-352: two smoothing passes over the stitched path ----------------------------
+    int pt_num = GlobalRoute.g_path_x.size();
+    if (pt_num >= 2) {
+        float start_pt[3] = {GlobalRoute.g_path_x[0], GlobalRoute.g_path_y[0], GlobalRoute.g_path_z[0]};
+        float end_pt[3] = {GlobalRoute.g_path_x[pt_num - 1], GlobalRoute.g_path_y[pt_num - 1], GlobalRoute.g_path_z[pt_num - 1]};
+        float **ctrl_pt = new float *[pt_num];
+        for (int i = 0; i < pt_num; ++i) {
+            ctrl_pt[i] = new float[3];
+            ctrl_pt[i][0] = GlobalRoute.g_path_x[i];
+            ctrl_pt[i][1] = GlobalRoute.g_path_y[i];
+            ctrl_pt[i][2] = GlobalRoute.g_path_z[i];
+        }
+        BS_Basic<float, 3, 0, 0, 0> smooth_curve(pt_num);
+        smooth_curve.SetParam(start_pt, end_pt, ctrl_pt, 150);
+        std::vector<float> smooth_x, smooth_y, smooth_z;
+        float res[3];
+        for (int i = 0; i < 16; i++) {          // "every 10 ticks until past 150"
+            smooth_curve.getCurvePoint(10.0f + (float)i * 10.0f, res);
+            smooth_x.push_back(res[0]); smooth_y.push_back(res[1]); smooth_z.push_back(res[2]);
+        }
+        fprintf(out, "smooth1 %d\n", (int)smooth_x.size());
+        for (size_t i = 0; i < smooth_x.size(); i++) fprintf(out, "%.9g %.9g %.9g\n", (double)smooth_x[i], (double)smooth_y[i], (double)smooth_z[i]);
+        const float constrain = 0.05;
+        pt_num = smooth_y.size();
+        float second_start_pt[9] = {GlobalRoute.g_path_x[0], GlobalRoute.g_path_y[0], GlobalRoute.g_path_z[0], 0, 0, 0, 0, 0, 0};
+        float second_end_pt[9] = {GlobalRoute.g_path_x[pt_num - 1], GlobalRoute.g_path_y[pt_num - 1], GlobalRoute.g_path_z[pt_num - 1], 0, 0, 0, 0, 0, 0};
+        float **second_pt = new float *[pt_num];
+        for (int i = 0; i < pt_num; ++i) {
+            second_pt[i] = new float[9];
+            second_pt[i][0] = smooth_x[i];
+            second_pt[i][1] = smooth_y[i];
+            second_pt[i][2] = smooth_z[i];
+            for (int j(3); j < 9; j++) second_pt[i][j] = constrain;
+        }
+        BS_Basic<float, 3, 2, 2, 2> second_curve(pt_num);
+        second_curve.SetParam(second_start_pt, second_end_pt, second_pt, 6000);
+        std::vector<float> s2;
+        second_curve.sample(50.0f, 50.0f, 121, s2);       // one launch instead of a clock() loop
+        float chk[3];
+        second_curve.getCurvePoint(50.0f + 60.0f * 50.0f, chk);
+        if (memcmp(chk, &s2[60 * 3], sizeof chk)) return 4;  // per-point and batched paths agree
+        fprintf(out, "smooth2 %d\n", (int)(s2.size() / 3));
+        for (size_t i = 0; i < s2.size() / 3; i++) fprintf(out, "%.9g %.9g %.9g\n", (double)s2[i * 3], (double)s2[i * 3 + 1], (double)s2[i * 3 + 2]);
+    }
     if (out != stdout) fclose(out);
     return 0;
 }

@@ -40,6 +40,8 @@ typedef enum {
 typedef struct wa_ctx wa_ctx;
 typedef struct wa_grid wa_grid;
 typedef struct wa_acs wa_acs;
+typedef struct wa_traj wa_traj;       /* device-resident polyline, n x 3 floats */
+typedef struct wa_bspline wa_bspline;
 
 /* ---- context --------------------------------------------------------------------------- */
 const char *wa_version(void);
@@ -165,6 +167,48 @@ typedef struct {
 int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32_t n_instances,
                   const wa_gtsp_params *p, int32_t *rand_state36, int32_t *tour_edges,
                   double *tour_cost, int32_t *iterations, double *pheromone_out);
+
+/* ---- path post-processing: what main.cpp:283-352 does with the planned path ----
+ * wa_traj_stitch replaces ACS_GTSP::read_all_segments / read_segment (ACS_GTSP.hpp:286-312): segment s
+ * is the node ids seg_ids[seg_off[s] .. seg_off[s+1]) (n_seg+1 offsets); coordinates come from the
+ * grid's axis tables on the device.  reverse (may be NULL) flips individual segments -- the reference
+ * appends best_matrix[i][j] as stored even when the tour runs j -> i. */
+int wa_traj_stitch(const wa_grid *g, const int64_t *seg_ids, const int64_t *seg_off, int32_t n_seg,
+                   const uint8_t *reverse, wa_traj **out);
+int wa_traj_from_points(wa_ctx *ctx, const float *xyz, int64_t n, wa_traj **out);
+int64_t wa_traj_size(const wa_traj *t);
+int wa_traj_read(const wa_traj *t, float *xyz /* n x 3 */);
+void wa_traj_destroy(wa_traj *t);
+
+/* BS_Basic<float, DIM, DEGREE, CONST_LEVEL_INI, CONST_LEVEL_FIN> (BSplineBasic.h:33-56); the template
+ * arguments are run-time values.  WA_ERR_ARG where the reference indexes out of bounds: dim outside
+ * 1..16, degree outside 0..7, a constraint level above the degree, or NumKnots < 2*(DEGREE+1) (:53-55). */
+int wa_bspline_create(wa_ctx *ctx, int32_t dim, int32_t degree, int32_t level_ini, int32_t level_fin,
+                      int64_t n_middle, wa_bspline **out);
+void wa_bspline_destroy(wa_bspline *b);
+/* The reference reads heap cells it never wrote when level_fin + 1 > degree (c_mat[idx][CL+1],
+ * BSplineBasic.h:414-431 -- BS_Basic<float,3,2,2,2> at main.cpp:337 does): their value is an input
+ * here, as a 32-bit float pattern.  Default 0 (a fresh zeroed heap). */
+int wa_bspline_set_uninit(wa_bspline *b, uint32_t float_bits);
+/* SetParam (:72-78).  init / fin: (level+1) x dim floats (position, velocity, acceleration ...);
+ * middle: n_middle rows of `stride` floats, the first dim of each are used (:458-464).  fin_time > 0. */
+int wa_bspline_set_param(wa_bspline *b, const float *init, const float *fin, const float *middle,
+                         int64_t stride, float fin_time);
+/* same with the middle points already on the device (dim must be 3, wa_traj_size == n_middle) */
+int wa_bspline_set_param_traj(wa_bspline *b, const float *init, const float *fin, const wa_traj *middle,
+                              float fin_time);
+int wa_bspline_info(const wa_bspline *b, int64_t *n_knots, int64_t *n_cps);
+int wa_bspline_read(const wa_bspline *b, float *knots, float *cps /* n_cps x dim */);
+/* getCurvePoint (:87-112, der = 0) / getCurveDerPoint (:122-146, der >= 1) for `count` times at once.
+ * ok[i] (may be NULL) = the reference's bool result; rows with ok = 0 are zero-filled (the reference
+ * leaves `ret` untouched). */
+int wa_bspline_eval(wa_bspline *b, const float *u, int64_t count, int32_t der, float *out /* count x dim */,
+                    uint8_t *ok);
+/* fixed-rate sampling u_i = t0 + (float)i * dt (fp32), replacing main.cpp's clock()-paced loops
+ * (:302-316, :341-351).  out / ok may be NULL; out_traj (may be NULL, needs dim == 3 and der == 0 or
+ * any der) receives the samples as a device-resident polyline, e.g. as the next spline's middle points. */
+int wa_bspline_sample(wa_bspline *b, float t0, float dt, int64_t count, int32_t der, float *out,
+                      uint8_t *ok, wa_traj **out_traj);
 
 #ifdef __cplusplus
 }

@@ -37,18 +37,22 @@ def run_demo(mode, seed, out):
 
 
 def parse(out):
-    d = dict(cost={}, edges=[], gpath=[])
+    d = dict(cost={}, edges=[], gpath=[], smooth1=[], smooth2=[])
+    cur = "gpath"
     for line in open(out):
         t = line.split()
-        if t[0] == "cost":
+        if t[0] in ("gpath", "smooth1", "smooth2"):
+            cur = t[0]
+        elif t[0] == "cost":
             d["cost"][(int(t[1]), int(t[2]))] = np.float32(t[3])
         elif t[0] == "tour_L":
             d["tour_L"], d["iters"] = float(t[1]), int(t[3])
         elif t[0] == "edge":
             d["edges"] += [int(t[1]), int(t[2])]
-        elif t[0] not in ("points", "gpath"):
-            d["gpath"].append([np.float32(v) for v in t])
-    d["gpath"] = np.array(d["gpath"], np.float32)
+        elif t[0] != "points":
+            d[cur].append([np.float32(v) for v in t])
+    for k in ("gpath", "smooth1", "smooth2"):
+        d[k] = np.array(d[k], np.float32).reshape(-1, 3)
     return d
 
 
@@ -82,6 +86,10 @@ def test_dropin_pipeline_ref_mode_equals_reference():
     assert np.array_equal(d["gpath"][:, 0].view(np.uint32), g["g_path_x"].view(np.uint32))
     assert np.array_equal(d["gpath"][:, 1].view(np.uint32), g["g_path_y"].view(np.uint32))
     assert np.array_equal(d["gpath"][:, 2].view(np.uint32), g["g_path_z"].view(np.uint32))
+    # main.cpp:287-352 through the drop-in BS_Basic: the reference's own two smoothing passes (fixed times)
+    sm = waf.load(os.path.join(G, "smooth_cubic_fill0.waf"))
+    assert np.array_equal(d["smooth1"].view(np.uint32).ravel(), sm["s1_samples"].view(np.uint32))
+    assert np.array_equal(d["smooth2"].view(np.uint32).ravel(), sm["s2_samples"].view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -68,6 +68,20 @@ SYMBOLS = {
     "wa_acs_debug_counters": (C.c_int, [_V, _P, _I]),
     "wa_acs_evaporate": (C.c_int, [_V, _I, _F, _I]),
     "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),
+    "wa_traj_stitch": (C.c_int, [_V, _P, _P, _I, _P, C.POINTER(_V)]),
+    "wa_traj_from_points": (C.c_int, [_V, _P, _I64, C.POINTER(_V)]),
+    "wa_traj_size": (_I64, [_V]),
+    "wa_traj_read": (C.c_int, [_V, _P]),
+    "wa_traj_destroy": (None, [_V]),
+    "wa_bspline_create": (C.c_int, [_V, _I, _I, _I, _I, _I64, C.POINTER(_V)]),
+    "wa_bspline_destroy": (None, [_V]),
+    "wa_bspline_set_uninit": (C.c_int, [_V, C.c_uint32]),
+    "wa_bspline_set_param": (C.c_int, [_V, _P, _P, _P, _I64, _F]),
+    "wa_bspline_set_param_traj": (C.c_int, [_V, _P, _P, _V, _F]),
+    "wa_bspline_info": (C.c_int, [_V, _P, _P]),
+    "wa_bspline_read": (C.c_int, [_V, _P, _P]),
+    "wa_bspline_eval": (C.c_int, [_V, _P, _I64, _I, _P, _P]),
+    "wa_bspline_sample": (C.c_int, [_V, _F, _F, _I64, _I, _P, _P, C.POINTER(_V)]),
 }
 
 _lib = None

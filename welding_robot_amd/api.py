@@ -244,6 +244,106 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_evaporate(self.h, slot, C.c_float(rho), repeats))
 
 
+class Trajectory:
+    """Device-resident polyline (n x 3 floats): a stitched path or a sampled spline."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        ctx._children.add(self)
+
+    @classmethod
+    def from_points(cls, ctx, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.wa_traj_from_points(ctx.h, _ptr(xyz), len(xyz), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def stitch(cls, grid, segments, reverse=None):
+        """ACS_GTSP::read_all_segments: `segments` = list of node-id arrays in tour order."""
+        segs = [np.ascontiguousarray(s, np.int64).reshape(-1) for s in segments]
+        ids = np.concatenate(segs) if segs else np.zeros(0, np.int64)
+        off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+        rev = np.ascontiguousarray(reverse, np.uint8) if reverse is not None else None
+        h = C.c_void_p()
+        ctx = grid.ctx
+        ctx.check(ctx.lib.wa_traj_stitch(grid.h, _ptr(ids), _ptr(off), len(segs), _ptr(rev), C.byref(h)))
+        return cls(ctx, h)
+
+    def __len__(self):
+        return int(self.ctx.lib.wa_traj_size(self.h))
+
+    def points(self):
+        out = np.empty((len(self), 3), np.float32)
+        self.ctx.check(self.ctx.lib.wa_traj_read(self.h, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wa_traj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Bspline:
+    """BS_Basic<float, dim, degree, level_ini, level_fin> (core/BSplineBasic.h) on the device."""
+
+    def __init__(self, ctx, dim, degree, level_ini, level_fin, n_middle, uninit_bits=0):
+        self.ctx, self.dim, self.degree, self.n_middle = ctx, dim, degree, n_middle
+        h = C.c_void_p()
+        ctx.check(ctx.lib.wa_bspline_create(ctx.h, dim, degree, level_ini, level_fin, n_middle, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        if uninit_bits:
+            ctx.check(ctx.lib.wa_bspline_set_uninit(self.h, uninit_bits))
+
+    def set_param(self, init, fin, middle, fin_time):
+        """SetParam; `middle` is an (n_middle, stride >= dim) array or a Trajectory."""
+        init = np.ascontiguousarray(init, np.float32)
+        fin = np.ascontiguousarray(fin, np.float32)
+        if isinstance(middle, Trajectory):
+            rc = self.ctx.lib.wa_bspline_set_param_traj(self.h, _ptr(init), _ptr(fin), middle.h, C.c_float(fin_time))
+        else:
+            middle = np.ascontiguousarray(middle, np.float32)
+            middle = middle.reshape(self.n_middle, -1) if middle.size else np.zeros((0, self.dim), np.float32)
+            rc = self.ctx.lib.wa_bspline_set_param(self.h, _ptr(init), _ptr(fin), _ptr(middle), middle.shape[1],
+                                                   C.c_float(fin_time))
+        self.ctx.check(rc)
+
+    def arrays(self):
+        nk, nc = C.c_int64(), C.c_int64()
+        self.ctx.check(self.ctx.lib.wa_bspline_info(self.h, C.byref(nk), C.byref(nc)))
+        knots, cps = np.empty(nk.value, np.float32), np.empty((nc.value, self.dim), np.float32)
+        self.ctx.check(self.ctx.lib.wa_bspline_read(self.h, _ptr(knots), _ptr(cps)))
+        return knots, cps
+
+    def eval(self, us, der=0):
+        us = np.ascontiguousarray(us, np.float32).reshape(-1)
+        out = np.empty((len(us), self.dim), np.float32)
+        ok = np.empty(len(us), np.uint8)
+        self.ctx.check(self.ctx.lib.wa_bspline_eval(self.h, _ptr(us), len(us), der, _ptr(out), _ptr(ok)))
+        return out, ok
+
+    def sample(self, t0, dt, count, der=0, host=True, device=False):
+        out = np.empty((count, self.dim), np.float32) if host else None
+        ok = np.empty(count, np.uint8) if host else None
+        th = C.c_void_p()
+        self.ctx.check(self.ctx.lib.wa_bspline_sample(self.h, C.c_float(t0), C.c_float(dt), count, der, _ptr(out),
+                                                      _ptr(ok), C.byref(th) if device else None))
+        traj = Trajectory(self.ctx, th) if device else None
+        return (out, ok, traj) if device else (out, ok)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wa_bspline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 def gtsp_solve(ctx, dist, cnt=None, mode=RNG_DEV, seed=1, stream=0, max_iterations=0, rand_state=None, want_pher=False):
     dist = np.ascontiguousarray(dist, np.float64)
     if dist.ndim == 2:

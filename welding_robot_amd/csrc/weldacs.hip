@@ -17,6 +17,7 @@
 #include "acs_kernels.hpp"
 #include "grid_kernels.hpp"
 #include "gtsp_kernels.hpp"
+#include "traj_kernels.hpp"
 
 // ------------------------------------------------------------------ handles
 struct wa_ctx {
@@ -35,6 +36,17 @@ struct wa_grid {
     int64_t n_free;
     float *cx, *cy, *cz;   // device
     uint8_t *occ;          // device
+};
+struct wa_traj {
+    wa_ctx *ctx;
+    int64_t n;
+    float *xyz;            // device, n x 3
+};
+struct wa_bspline {
+    wa_ctx *ctx;
+    WaSpline S;            // knots / cps on the device
+    float *d_ends;         // init rows + fin rows staged for k_bspline_setup
+    bool set;
 };
 struct EvPair { hipEvent_t a, b; int cls; };
 struct wa_acs {
@@ -936,6 +948,266 @@ int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32
     }
     if (rand_state36 && p->rng_mode == WA_RNG_REF) { memcpy(rand_state36, r.r, sizeof(int32_t) * 34); rand_state36[34] = r.f; rand_state36[35] = r.b; }
     return WA_OK;
+}
+
+// ------------------------------------------------------------------ path post-processing
+static int traj_alloc(wa_ctx *ctx, int64_t n, wa_traj **out)
+{
+    wa_traj *t = new wa_traj();
+    t->ctx = ctx;
+    t->n = n;
+    t->xyz = nullptr;
+    if (dalloc(&t->xyz, (size_t)n * 3)) {
+        delete t;
+        return fail(ctx, WA_ERR_ALLOC, "trajectory device allocation failed");
+    }
+    *out = t;
+    return WA_OK;
+}
+
+int wa_traj_from_points(wa_ctx *ctx, const float *xyz, int64_t n, wa_traj **out)
+{
+    if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return fail(ctx, WA_ERR_ARG, "wa_traj_from_points: bad argument");
+    wa_traj *t = nullptr;
+    int rc = traj_alloc(ctx, n, &t);
+    if (rc) return rc;
+    if (n) {
+        hipError_t h = hipMemcpyAsync(t->xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+        h = h ? h : hipStreamSynchronize(ctx->stream);
+        if (h != hipSuccess) { wa_traj_destroy(t); return fail(ctx, WA_ERR_DEVICE, "wa_traj_from_points: %s", hipGetErrorString(h)); }
+    }
+    *out = t;
+    return WA_OK;
+}
+
+int wa_traj_stitch(const wa_grid *g, const int64_t *seg_ids, const int64_t *seg_off, int32_t n_seg,
+                   const uint8_t *reverse, wa_traj **out)
+{
+    if (!g) return WA_ERR_ARG;
+    wa_ctx *ctx = g->ctx;
+    if (!out || n_seg < 0 || !seg_off) return fail(ctx, WA_ERR_ARG, "wa_traj_stitch: bad argument");
+    if (seg_off[0] != 0) return fail(ctx, WA_ERR_ARG, "wa_traj_stitch: seg_off[0] must be 0");
+    for (int32_t s = 0; s < n_seg; s++)
+        if (seg_off[s + 1] < seg_off[s]) return fail(ctx, WA_ERR_ARG, "wa_traj_stitch: seg_off must be non-decreasing");
+    int64_t n = seg_off[n_seg];
+    if (n > 0 && !seg_ids) return fail(ctx, WA_ERR_ARG, "wa_traj_stitch: seg_ids is NULL");
+    for (int64_t i = 0; i < n; i++)
+        if (seg_ids[i] < 0 || seg_ids[i] >= g->d.n) return fail(ctx, WA_ERR_ARG, "wa_traj_stitch: node id outside the grid");
+    wa_traj *t = nullptr;
+    int rc = traj_alloc(ctx, n, &t);
+    if (rc) return rc;
+    if (n) {
+        long long *d_ids = nullptr, *d_off = nullptr;
+        uint8_t *d_rev = nullptr;
+        hipError_t h = dalloc(&d_ids, (size_t)n);
+        h = h ? h : dalloc(&d_off, (size_t)n_seg + 1);
+        if (reverse) h = h ? h : dalloc(&d_rev, (size_t)n_seg);
+        h = h ? h : hipMemcpyAsync(d_ids, seg_ids, sizeof(long long) * n, hipMemcpyHostToDevice, ctx->stream);
+        h = h ? h : hipMemcpyAsync(d_off, seg_off, sizeof(long long) * (n_seg + 1), hipMemcpyHostToDevice, ctx->stream);
+        if (reverse) h = h ? h : hipMemcpyAsync(d_rev, reverse, (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream);
+        if (h == hipSuccess) {
+            k_stitch<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_ids, d_off, n_seg, d_rev, g->d, g->cx, g->cy, g->cz, t->xyz, n);
+            h = hipGetLastError();
+        }
+        h = h ? h : hipStreamSynchronize(ctx->stream);
+        hipFree(d_ids); hipFree(d_off); hipFree(d_rev);
+        if (h != hipSuccess) { wa_traj_destroy(t); return fail(ctx, WA_ERR_DEVICE, "wa_traj_stitch: %s", hipGetErrorString(h)); }
+    }
+    *out = t;
+    return WA_OK;
+}
+
+int64_t wa_traj_size(const wa_traj *t) { return t ? t->n : -1; }
+int wa_traj_read(const wa_traj *t, float *xyz)
+{
+    if (!t || (t->n > 0 && !xyz)) return WA_ERR_ARG;
+    if (t->n) HIPC(t->ctx, hipMemcpy(xyz, t->xyz, sizeof(float) * 3 * t->n, hipMemcpyDeviceToHost));
+    return WA_OK;
+}
+void wa_traj_destroy(wa_traj *t)
+{
+    if (!t) return;
+    hipFree(t->xyz);
+    delete t;
+}
+
+int wa_bspline_create(wa_ctx *ctx, int32_t dim, int32_t degree, int32_t level_ini, int32_t level_fin,
+                      int64_t n_middle, wa_bspline **out)
+{
+    if (!ctx || !out) return fail(ctx, WA_ERR_ARG, "wa_bspline_create: null argument");
+    if (dim < 1 || dim > WA_BS_MAX_DIM) return fail(ctx, WA_ERR_ARG, "wa_bspline_create: dim must be 1..16");
+    if (degree < 0 || degree > WA_BS_MAX_DEGREE) return fail(ctx, WA_ERR_ARG, "wa_bspline_create: degree must be 0..7");
+    if (level_ini < 0 || level_fin < 0 || level_ini > degree || level_fin > degree)
+        return fail(ctx, WA_ERR_ARG, "wa_bspline_create: constraint levels must be 0..degree");
+    if (n_middle < 0) return fail(ctx, WA_ERR_ARG, "wa_bspline_create: n_middle < 0");
+    int64_t nk = degree + n_middle + 2 + level_ini + level_fin + 1;   // BSplineBasic.h:38-39
+    int64_t nc = n_middle + 2 + level_ini + level_fin;                // :40
+    if (nk < 2 * (degree + 1)) return fail(ctx, WA_ERR_ARG, "wa_bspline_create: invalid setup (num_knots < 2*(degree+1))");
+    wa_bspline *b = new wa_bspline();
+    b->ctx = ctx;
+    b->S.dim = dim; b->S.degree = degree; b->S.ci = level_ini; b->S.cf = level_fin;
+    b->S.n_middle = n_middle; b->S.n_knots = nk; b->S.n_cps = nc;
+    b->S.knots = nullptr; b->S.cps = nullptr; b->S.uninit = 0.0f;
+    b->d_ends = nullptr;
+    b->set = false;
+    hipError_t h = dalloc(&b->S.knots, (size_t)nk);
+    h = h ? h : dalloc(&b->S.cps, (size_t)nc * dim);
+    h = h ? h : dalloc(&b->d_ends, (size_t)(level_ini + level_fin + 2) * dim);
+    h = h ? h : hipMemsetAsync(b->S.knots, 0, sizeof(float) * nk, ctx->stream);         // constructor zero-fills (:44-51)
+    h = h ? h : hipMemsetAsync(b->S.cps, 0, sizeof(float) * nc * dim, ctx->stream);
+    h = h ? h : hipStreamSynchronize(ctx->stream);
+    if (h != hipSuccess) { wa_bspline_destroy(b); return fail(ctx, WA_ERR_ALLOC, "wa_bspline_create: %s", hipGetErrorString(h)); }
+    *out = b;
+    return WA_OK;
+}
+
+void wa_bspline_destroy(wa_bspline *b)
+{
+    if (!b) return;
+    hipFree(b->S.knots); hipFree(b->S.cps); hipFree(b->d_ends);
+    delete b;
+}
+
+int wa_bspline_set_uninit(wa_bspline *b, uint32_t float_bits)
+{
+    if (!b) return WA_ERR_ARG;
+    memcpy(&b->S.uninit, &float_bits, 4);
+    return WA_OK;
+}
+
+static int bspline_setup(wa_bspline *b, const float *init, const float *fin, const float *d_middle, int64_t stride,
+                         float fin_time)
+{
+    wa_ctx *ctx = b->ctx;
+    const WaSpline &S = b->S;
+    size_t ni = (size_t)(S.ci + 1) * S.dim, nf = (size_t)(S.cf + 1) * S.dim;
+    std::vector<float> ends(ni + nf);
+    memcpy(ends.data(), init, sizeof(float) * ni);
+    memcpy(ends.data() + ni, fin, sizeof(float) * nf);
+    HIPC(ctx, hipMemcpyAsync(b->d_ends, ends.data(), sizeof(float) * (ni + nf), hipMemcpyHostToDevice, ctx->stream));
+    k_bspline_setup<<<1, 64, 0, ctx->stream>>>(S, b->d_ends, fin_time);
+    HIPC(ctx, hipGetLastError());
+    if (S.n_middle) {
+        long long total = S.n_middle * S.dim;
+        k_bspline_middle<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(S, d_middle, stride);
+        HIPC(ctx, hipGetLastError());
+    }
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));   // `ends` is host-stack staging
+    b->set = true;
+    return WA_OK;
+}
+
+int wa_bspline_set_param(wa_bspline *b, const float *init, const float *fin, const float *middle, int64_t stride,
+                         float fin_time)
+{
+    if (!b) return WA_ERR_ARG;
+    wa_ctx *ctx = b->ctx;
+    if (!init || !fin || (b->S.n_middle > 0 && !middle)) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param: null argument");
+    if (stride < b->S.dim) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param: stride < dim");
+    if (!(fin_time > 0.0f) || !isfinite(fin_time)) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param: fin_time must be finite and > 0");
+    float *d_mid = nullptr;
+    if (b->S.n_middle) {
+        if (dalloc(&d_mid, (size_t)b->S.n_middle * stride)) return fail(ctx, WA_ERR_ALLOC, "wa_bspline_set_param: staging");
+        hipError_t h = hipMemcpyAsync(d_mid, middle, sizeof(float) * b->S.n_middle * stride, hipMemcpyHostToDevice, ctx->stream);
+        if (h != hipSuccess) { hipFree(d_mid); return fail(ctx, WA_ERR_DEVICE, "wa_bspline_set_param: %s", hipGetErrorString(h)); }
+    }
+    int rc = bspline_setup(b, init, fin, d_mid, stride, fin_time);
+    hipFree(d_mid);
+    return rc;
+}
+
+int wa_bspline_set_param_traj(wa_bspline *b, const float *init, const float *fin, const wa_traj *middle, float fin_time)
+{
+    if (!b) return WA_ERR_ARG;
+    wa_ctx *ctx = b->ctx;
+    if (!init || !fin || !middle) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param_traj: null argument");
+    if (b->S.dim != 3) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param_traj: dim must be 3");
+    if (middle->n != b->S.n_middle) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param_traj: trajectory size != n_middle");
+    if (!(fin_time > 0.0f) || !isfinite(fin_time)) return fail(ctx, WA_ERR_ARG, "wa_bspline_set_param_traj: fin_time must be finite and > 0");
+    return bspline_setup(b, init, fin, middle->xyz, 3, fin_time);
+}
+
+int wa_bspline_info(const wa_bspline *b, int64_t *n_knots, int64_t *n_cps)
+{
+    if (!b) return WA_ERR_ARG;
+    if (n_knots) *n_knots = b->S.n_knots;
+    if (n_cps) *n_cps = b->S.n_cps;
+    return WA_OK;
+}
+
+int wa_bspline_read(const wa_bspline *b, float *knots, float *cps)
+{
+    if (!b) return WA_ERR_ARG;
+    if (knots) HIPC(b->ctx, hipMemcpy(knots, b->S.knots, sizeof(float) * b->S.n_knots, hipMemcpyDeviceToHost));
+    if (cps) HIPC(b->ctx, hipMemcpy(cps, b->S.cps, sizeof(float) * b->S.n_cps * b->S.dim, hipMemcpyDeviceToHost));
+    return WA_OK;
+}
+
+static hipError_t bspline_launch(wa_bspline *b, const float *d_u, float t0, float dt, int64_t count, int32_t der,
+                                 float *d_out, uint8_t *d_ok)
+{
+    hipStream_t st = b->ctx->stream;
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    switch (b->S.degree) {
+#define WA_BS_CASE(D) case D: k_bspline_eval<D><<<blocks, 256, 0, st>>>(b->S, d_u, t0, dt, count, der, d_out, d_ok); break;
+        WA_BS_CASE(0) WA_BS_CASE(1) WA_BS_CASE(2) WA_BS_CASE(3) WA_BS_CASE(4) WA_BS_CASE(5) WA_BS_CASE(6) WA_BS_CASE(7)
+#undef WA_BS_CASE
+    }
+    return hipGetLastError();
+}
+
+static int bspline_run(wa_bspline *b, const float *u, float t0, float dt, int64_t count, int32_t der, float *out,
+                       uint8_t *ok, wa_traj **out_traj, const char *who)
+{
+    wa_ctx *ctx = b->ctx;
+    if (!b->set) return fail(ctx, WA_ERR_STATE, "%s: SetParam has not run", who);
+    if (count < 0 || der < 0) return fail(ctx, WA_ERR_ARG, "%s: bad count / derivative level", who);
+    if (out_traj && b->S.dim != 3) return fail(ctx, WA_ERR_ARG, "%s: a trajectory output needs dim == 3", who);
+    if (out_traj) *out_traj = nullptr;
+    if (count == 0) return out_traj ? traj_alloc(ctx, 0, out_traj) : WA_OK;
+    const int dim = b->S.dim;
+    float *d_u = nullptr, *d_out = nullptr;
+    uint8_t *d_ok = nullptr;
+    wa_traj *t = nullptr;
+    hipError_t h = hipSuccess;
+    if (out_traj) {
+        int rc = traj_alloc(ctx, count, &t);
+        if (rc) return rc;
+        d_out = t->xyz;
+    } else {
+        h = dalloc(&d_out, (size_t)count * dim);
+    }
+    if (u) {
+        h = h ? h : dalloc(&d_u, (size_t)count);
+        h = h ? h : hipMemcpyAsync(d_u, u, sizeof(float) * count, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (ok) h = h ? h : dalloc(&d_ok, (size_t)count);
+    h = h ? h : bspline_launch(b, d_u, t0, dt, count, der, d_out, d_ok);
+    if (out) h = h ? h : hipMemcpyAsync(out, d_out, sizeof(float) * count * dim, hipMemcpyDeviceToHost, ctx->stream);
+    if (ok) h = h ? h : hipMemcpyAsync(ok, d_ok, (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+    h = h ? h : hipStreamSynchronize(ctx->stream);
+    hipFree(d_u); hipFree(d_ok);
+    if (!out_traj) hipFree(d_out);
+    if (h != hipSuccess) {
+        wa_traj_destroy(t);
+        return fail(ctx, WA_ERR_DEVICE, "B-spline evaluation: %s", hipGetErrorString(h));
+    }
+    if (out_traj) *out_traj = t;
+    return WA_OK;
+}
+
+int wa_bspline_eval(wa_bspline *b, const float *u, int64_t count, int32_t der, float *out, uint8_t *ok)
+{
+    if (!b) return WA_ERR_ARG;
+    if (count > 0 && (!u || !out)) return fail(b->ctx, WA_ERR_ARG, "wa_bspline_eval: null argument");
+    return bspline_run(b, u, 0.0f, 0.0f, count, der, out, ok, nullptr, "wa_bspline_eval");
+}
+
+int wa_bspline_sample(wa_bspline *b, float t0, float dt, int64_t count, int32_t der, float *out, uint8_t *ok,
+                      wa_traj **out_traj)
+{
+    if (!b) return WA_ERR_ARG;
+    return bspline_run(b, nullptr, t0, dt, count, der, out, ok, out_traj, "wa_bspline_sample");
 }
 
 }  // extern "C"
