@@ -22,7 +22,7 @@
 //   sort      n= seed= levels=                 std::sort permutation on tied float keys
 //   voxelize  stl= p= wall= [gridout=]         STLReader + GridMap::creatGridMap
 //   acs       (stl= p= wall= | gridin=) (snode=z,y,x enode=z,y,x | spt=x,y,z ept=x,y,z)
-//             seed= iters= predict= [driven=0|1] [fixed=N] [dumppher=1]
+//             seed= iters= predict= [driven=0|1] [fixed=N] [dumppher=1] [nb=6|26]
 //   pairs     (stl= p= wall= | gridin=) pts=FILE predict= seed= graph=FILE [gtsp=1]
 //   gtsp      graph=FILE seed=
 //   bspline   deg= ci= cf= n= seed= tf= [fill=HEX] [t0= dt= count=]   BS_Basic<float,3,deg,ci,cf>
@@ -201,13 +201,14 @@ static void dump_pheromone(Waf &w, ACS_Rank &s, bool full)
 {
     int nx = s.rangeX, ny = s.rangeY, nz = s.rangeZ;
     std::vector<float> ph;
-    if (full) ph.reserve((size_t)nx * ny * nz * 6);
+    const int nb = (int)s.nodes[0][0][0].adjacency_infos.size();   // 6, or 26 after widen_to_26()
+    if (full) ph.reserve((size_t)nx * ny * nz * nb);
     double sum = 0;
     uint64_t hx = 0;
     for (int z = 0; z < nz; z++)
         for (int y = 0; y < ny; y++)
             for (int x = 0; x < nx; x++)
-                for (int k = 0; k < 6; k++) {
+                for (int k = 0; k < nb; k++) {
                     float v = s.nodes[z][y][x].adjacency_infos[k].pheromone;
                     uint32_t bits;
                     memcpy(&bits, &v, 4);
@@ -218,6 +219,39 @@ static void dump_pheromone(Waf &w, ACS_Rank &s, bool full)
     w.one_f64("pher_sum", sum);
     w.one_i64("pher_hash", (int64_t)hx);
     if (full) w.f32("pher", ph);
+}
+
+// the 26-neighbour variant the reference stubs out.  initFromGridMap walks the 3x3x3
+// cube around every node but sets the distance of edge (two non-zero offsets) and corner (three)
+// neighbours to 0, which skips them; the intended values stand in comments next to it
+// (`precision * 1.414f`, `precision * 1.732f`, ACSRank_3D.hpp:380,:383).  This rebuilds the adjacency
+// lists with those two values in force -- same cube order, same out-of-bounds convention (self pointer
+// with an all-zero record) -- so that the reference's own selectNext / update_pheromone / Agent code
+// runs on 26 neighbours.  Only the driven loop can be used afterwards (computeSolution's evaporation
+// loop is hard-wired to 6 entries).
+static void widen_to_26(ACS_Rank &s)
+{
+    for (int z = 0; z < s.rangeZ; z++)
+        for (int y = 0; y < s.rangeY; y++)
+            for (int x = 0; x < s.rangeX; x++) {
+                ACS_Node<float> &nd = s.nodes[z][y][x];
+                nd.adjacency_nodes.clear();
+                nd.adjacency_infos.clear();
+                for (int i = -1; i <= 1; i++)
+                    for (int j = -1; j <= 1; j++)
+                        for (int k = -1; k <= 1; k++) {
+                            int type = (i != 0) + (j != 0) + (k != 0);
+                            if (type == 0) continue;
+                            float distance = type == 1 ? s.precision : type == 2 ? s.precision * 1.414f : s.precision * 1.732f;
+                            if (x + k >= s.rangeX || x + k < 0 || y + j >= s.rangeY || y + j < 0 || z + i >= s.rangeZ || z + i < 0) {
+                                nd.adjacency_nodes.push_back(&nd);
+                                nd.adjacency_infos.push_back(_Inf_of_Points_t<float>(0, 0, 0));
+                            } else {
+                                nd.adjacency_nodes.push_back(&s.nodes[z + i][y + j][x + k]);
+                                nd.adjacency_infos.push_back(_Inf_of_Points_t<float>(distance, s.pheromone_0, 0));
+                            }
+                        }
+            }
 }
 
 // Re-drive of the generation loop through the reference's own members, so that a per
@@ -254,7 +288,9 @@ static void drive(ACS_Rank &s, float predict, int iters, int fixed, Trace &tr)
         }
         double t1 = now_s();
         for_each_nodes(s.nodes, s.rangeX, s.rangeY, s.rangeZ, [&](int z, int y, int x) {
-            for (int k = 0; k < 6; k++) s.nodes[z][y][x].adjacency_infos[k].pheromone *= s.rho;
+            // ACSRank_3D.hpp:270 hard-wires 6; with nb=26 every adjacency entry evaporates
+            const int nb = (int)s.nodes[z][y][x].adjacency_infos.size();
+            for (int k = 0; k < nb; k++) s.nodes[z][y][x].adjacency_infos[k].pheromone *= s.rho;
         });
         double t2 = now_s();
         std::sort(s.agents.begin(), s.agents.end(),
@@ -349,9 +385,11 @@ static int cmd_acs(const Args &a, Waf &w)
     int iters = (int)getl(a, "iters", 150);
     float predict = getf(a, "predict", 10.f);
     int fixed = (int)getl(a, "fixed", 0);
-    bool driven = getl(a, "driven", 0) != 0 || fixed > 0;
+    int nb = (int)getl(a, "nb", 6);
+    bool driven = getl(a, "driven", 0) != 0 || fixed > 0 || nb == 26;
     double t0 = now_s();
     s.initFromGridMap();
+    if (nb == 26) widen_to_26(s);
     double t_init = now_s() - t0;
     s.max_iteration = iters;
     srand((unsigned)seed);

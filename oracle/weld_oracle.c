@@ -368,7 +368,10 @@ struct wo_acs {
     float precision;
     float *cx, *cy, *cz;
     uint8_t *free_;
-    float *pher;          /* [n][6] */
+    int nb;               /* neighbourhood: 6 (the reference as shipped) or 26 (its stubbed variant, :361-388) */
+    const int *dx, *dy, *dz;
+    float dist[26];       /* step length per edge (:369-385) */
+    float *pher;          /* [n][nb] */
     uint32_t *visit;      /* tabu stamps, one array reused by all ants */
     uint32_t visit_stamp;
     uint32_t *bestmark;   /* best-path membership stamps */
@@ -390,10 +393,32 @@ static void ant_push(wo_ant *a, int32_t id, int8_t ch)
     a->len++;
 }
 
+static const int DX[6] = {0, 0, -1, 1, 0, 0}, DY[6] = {0, -1, 0, 0, 1, 0}, DZ[6] = {-1, 0, 0, 0, 0, 1};
+/* the 3x3x3 cube around a node in the reference's loop order z (outer), y, x (inner), centre skipped (:352-357) */
+static const int DX26[26] = {-1, 0, 1, -1, 0, 1, -1, 0, 1, -1, 0, 1, -1, 1, -1, 0, 1, -1, 0, 1, -1, 0, 1, -1, 0, 1};
+static const int DY26[26] = {-1, -1, -1, 0, 0, 0, 1, 1, 1, -1, -1, -1, 0, 0, 1, 1, 1, -1, -1, -1, 0, 0, 0, 1, 1, 1};
+static const int DZ26[26] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+
 wo_acs *wo_acs_create(int32_t nx, int32_t ny, int32_t nz, const float *cx, const float *cy,
                       const float *cz, const uint8_t *free_, float precision, float pheromone_0)
 {
+    return wo_acs_create_nb(nx, ny, nz, cx, cy, cz, free_, precision, pheromone_0, 6);
+}
+
+/* nb = 26: initFromGridMap with the two distances the author commented out restored
+ * (`precision * 1.414f` for edge neighbours :380, `precision * 1.732f` for corner neighbours :383) and
+ * the evaporation / reset loops (:270, :312, hard-wired to 6) covering every adjacency entry. */
+wo_acs *wo_acs_create_nb(int32_t nx, int32_t ny, int32_t nz, const float *cx, const float *cy,
+                         const float *cz, const uint8_t *free_, float precision, float pheromone_0, int32_t nb)
+{
+    if (nb != 6 && nb != 26) return NULL;
     wo_acs *s = (wo_acs *)calloc(1, sizeof(wo_acs));
+    s->nb = nb;
+    s->dx = nb == 6 ? DX : DX26; s->dy = nb == 6 ? DY : DY26; s->dz = nb == 6 ? DZ : DZ26;
+    for (int k = 0; k < nb; k++) {
+        int type = (s->dx[k] != 0) + (s->dy[k] != 0) + (s->dz[k] != 0);
+        s->dist[k] = type == 1 ? precision : type == 2 ? precision * 1.414f : precision * 1.732f;
+    }
     s->nx = nx; s->ny = ny; s->nz = nz;
     s->n = (int64_t)nx * ny * nz;
     s->precision = precision;
@@ -401,7 +426,7 @@ wo_acs *wo_acs_create(int32_t nx, int32_t ny, int32_t nz, const float *cx, const
     s->cy = (float *)malloc(sizeof(float) * ny); memcpy(s->cy, cy, sizeof(float) * ny);
     s->cz = (float *)malloc(sizeof(float) * nz); memcpy(s->cz, cz, sizeof(float) * nz);
     s->free_ = (uint8_t *)malloc((size_t)s->n); memcpy(s->free_, free_, (size_t)s->n);
-    s->pher = (float *)malloc(sizeof(float) * 6 * (size_t)s->n);
+    s->pher = (float *)malloc(sizeof(float) * (size_t)nb * (size_t)s->n);
     s->visit = (uint32_t *)calloc((size_t)s->n, sizeof(uint32_t));
     s->bestmark = (uint32_t *)calloc((size_t)s->n, sizeof(uint32_t));
     s->best.L = INFINITY;
@@ -409,13 +434,11 @@ wo_acs *wo_acs_create(int32_t nx, int32_t ny, int32_t nz, const float *cx, const
     for (int32_t z = 0; z < nz; z++)
         for (int32_t y = 0; y < ny; y++)
             for (int32_t x = 0; x < nx; x++) {
-                float *p = s->pher + 6 * (((size_t)z * ny + y) * nx + x);
-                p[0] = z > 0 ? pheromone_0 : 0.f;
-                p[1] = y > 0 ? pheromone_0 : 0.f;
-                p[2] = x > 0 ? pheromone_0 : 0.f;
-                p[3] = x < nx - 1 ? pheromone_0 : 0.f;
-                p[4] = y < ny - 1 ? pheromone_0 : 0.f;
-                p[5] = z < nz - 1 ? pheromone_0 : 0.f;
+                float *p = s->pher + (size_t)nb * (((size_t)z * ny + y) * nx + x);
+                for (int k = 0; k < nb; k++) {
+                    int32_t X = x + s->dx[k], Y = y + s->dy[k], Z = z + s->dz[k];
+                    p[k] = (X < 0 || X >= nx || Y < 0 || Y >= ny || Z < 0 || Z >= nz) ? 0.f : pheromone_0;
+                }
             }
     return s;
 }
@@ -429,7 +452,7 @@ void wo_acs_destroy(wo_acs *s)
 
 void wo_acs_reset(wo_acs *s, float pheromone_0)
 { /* :307-315 -- every edge, the out-of-bounds ones included */
-    for (int64_t i = 0; i < 6 * s->n; i++) s->pher[i] = pheromone_0;
+    for (int64_t i = 0; i < s->nb * s->n; i++) s->pher[i] = pheromone_0;
 }
 
 /* power() :48-60, T = float */
@@ -457,8 +480,6 @@ static float heuristic_term(const wo_acs *s, int32_t x, int32_t y, int32_t z, in
     return 1 + beta * c;
 }
 
-static const int DX[6] = {0, 0, -1, 1, 0, 0}, DY[6] = {0, -1, 0, 0, 1, 0}, DZ[6] = {-1, 0, 0, 0, 0, 1};
-
 void wo_acs_heuristic(const wo_acs *s, int64_t end_id, float beta, float *out)
 {
     int32_t ex = (int32_t)(end_id % s->nx), ey = (int32_t)((end_id / s->nx) % s->ny),
@@ -466,9 +487,9 @@ void wo_acs_heuristic(const wo_acs *s, int64_t end_id, float beta, float *out)
     for (int32_t z = 0; z < s->nz; z++)
         for (int32_t y = 0; y < s->ny; y++)
             for (int32_t x = 0; x < s->nx; x++)
-                for (int k = 0; k < 6; k++) {
-                    int32_t X = x + DX[k], Y = y + DY[k], Z = z + DZ[k];
-                    size_t o = 6 * (((size_t)z * s->ny + y) * s->nx + x) + k;
+                for (int k = 0; k < s->nb; k++) {
+                    int32_t X = x + s->dx[k], Y = y + s->dy[k], Z = z + s->dz[k];
+                    size_t o = (size_t)s->nb * (((size_t)z * s->ny + y) * s->nx + x) + k;
                     if (X < 0 || X >= s->nx || Y < 0 || Y >= s->ny || Z < 0 || Z >= s->nz) out[o] = 0.f;
                     else out[o] = heuristic_term(s, x, y, z, X, Y, Z, ex, ey, ez, beta);
                 }
@@ -490,17 +511,19 @@ static void walk_ant(wo_acs *s, const wo_acs_params *p, wo_ant *a, int64_t start
     uint32_t step = 0;
     for (;;) {
         int32_t x = (int32_t)(cur % nx), y = (int32_t)((cur / nx) % ny), z = (int32_t)(cur / ((int64_t)nx * ny));
-        float info[6];
-        int adm[6], nadm = 0;
+        const int NB = s->nb;
+        const int *DX = s->dx, *DY = s->dy, *DZ = s->dz;
+        float info[26];
+        int adm[26], nadm = 0;
         float total = 0;
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < NB; k++) {
             adm[k] = 0;
             int32_t X = x + DX[k], Y = y + DY[k], Z = z + DZ[k];
             if (X < 0 || X >= nx || Y < 0 || Y >= ny || Z < 0 || Z >= nz) continue; /* self-pointer :148,:395 */
             int64_t nb = ((int64_t)Z * ny + Y) * nx + X;
             if (s->visit[nb] == stamp) continue; /* tabu :145-146 */
             if (!s->free_[nb]) continue;        /* :148 */
-            info[k] = powi_f(s->pher[cur * 6 + k], p->alpha) *
+            info[k] = powi_f(s->pher[cur * NB + k], p->alpha) *
                       heuristic_term(s, x, y, z, X, Y, Z, ex, ey, ez, p->beta); /* :154 */
             total += info[k];                                                   /* :155 */
             adm[k] = 1;
@@ -513,7 +536,7 @@ static void walk_ant(wo_acs *s, const wo_acs_params *p, wo_ant *a, int64_t start
         rnd *= total;
         float prob = 0;
         int pick = -1;
-        for (int k = 5; k >= 0; k--) { /* reverse cumulative order :172-189 */
+        for (int k = NB - 1; k >= 0; k--) { /* reverse cumulative order :172-189 */
             if (!adm[k]) continue;
             prob += info[k];
             if (prob >= rnd) { pick = k; break; }
@@ -522,7 +545,7 @@ static void walk_ant(wo_acs *s, const wo_acs_params *p, wo_ant *a, int64_t start
         int64_t nb = ((int64_t)(z + DZ[pick]) * ny + (y + DY[pick])) * nx + (x + DX[pick]);
         s->visit[nb] = stamp;
         ant_push(a, (int32_t)nb, (int8_t)pick);
-        a->L += s->precision; /* :78, distance == precision :378 */
+        a->L += s->dist[pick]; /* :78; distance == precision for the six face neighbours :378 */
         step++;
         if (nb == end) return; /* :182-186 */
         cur = nb;
@@ -583,7 +606,7 @@ int32_t wo_acs_solve(wo_acs *s, const wo_acs_params *p, int64_t start_id, int64_
             steps += ants[a].len - 1;
         }
         double t1 = now_s();
-        for (int64_t i = 0; i < 6 * s->n; i++) s->pher[i] *= p->rho; /* :268-272 */
+        for (int64_t i = 0; i < s->nb * s->n; i++) s->pher[i] *= p->rho; /* :268-272 */
         double t2 = now_s();
         for (int32_t a = 0; a < colony; a++) keys[a] = ants[a].L;
         if (p->rng_mode == WO_RNG_REF) wo_std_sort_perm(keys, colony, perm); /* :273-274 */
@@ -596,7 +619,7 @@ int32_t wo_acs_solve(wo_acs *s, const wo_acs_params *p, int64_t start_id, int64_
                 int32_t v = a->ids[i], w = a->ids[i + 1];
                 int k = a->choice[i + 1];
                 int onbest = s->bestmark[v] == s->best_ver && s->bestmark[w] == s->best_ver; /* :209 */
-                s->pher[(size_t)v * 6 + k] += (lambda - (float)o) * Q / a->L + (float)onbest * lambda * Q / s->best.L;
+                s->pher[(size_t)v * s->nb + k] += (lambda - (float)o) * Q / a->L + (float)onbest * lambda * Q / s->best.L;
             }
         }
         double t4 = now_s();

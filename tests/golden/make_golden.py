@@ -85,11 +85,43 @@ def gen_smooth():
         print("smooth", fill, len(pr["g_path_x"]), pr["s2_samples"].reshape(-1, 3)[[0, 60, -1]])
 
 
+def gen_nb26():
+    """reference member functions on 26-neighbour adjacency (harness nb=26, always driven)."""
+    cubic = os.path.join(HERE, "cubic.stl")
+    piece = os.path.join(HERE, "simplified_piece.stl")
+    cases = [
+        ("acs_cubic_nb26_adaptive", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=50, predict="1.03", nb=26)),
+        ("acs_cubic_nb26_fixed16", dict(stl=cubic, p="0.0219", wall=8, snode="4,4,4", enode="20,27,20", seed=777, iters=50, predict="1.03", fixed=16, nb=26)),
+        ("acs_cubic_nb26_seam", dict(stl=cubic, p="0.0225", wall=8, snode="4,4,4", enode="20,27,20", seed=12345, iters=10, predict="1.03", nb=26)),
+        ("acs_piece_nb26_fixed128", dict(stl=piece, p="0.0148", wall=4, snode="0,0,0", enode="22,32,63", seed=12345, iters=100, predict="5.4126", fixed=128, nb=26)),
+    ]
+    for tag, kw in cases:
+        a = O.run_ref("acs", TMP + "/a.waf", **kw)
+        out = keep(a, ACS_KEYS)
+        out["args"] = np.frombuffer(repr(sorted((k, str(v) if k != "stl" else os.path.basename(v)) for k, v in kw.items())).encode(), np.uint8)
+        waf.save(HERE + "/%s.waf" % tag, out)
+        print(tag, a["best_L"], len(a["best_path"]), a["tr_steps"][:4])
+    g = O.synth_grid(64, seed=77, occ_prob=0.10)
+    gin = TMP + "/synth64.in"
+    O.write_grid_in(g, gin)
+    kw = dict(gridin=gin, spt="0,0,0", ept="63,63,63", seed=4242, iters=6, predict="200", fixed=64, nb=26)
+    a = O.run_ref("acs", TMP + "/a.waf", **kw)
+    out = keep(a, ACS_KEYS)
+    out["args"] = np.frombuffer(repr(sorted((k, str(v)) for k, v in kw.items() if k != "gridin")).encode(), np.uint8)
+    h = O.fnv1a_bytes(g.free.tobytes())
+    out["grid_fnv"] = np.array([h - (1 << 64) if h >= (1 << 63) else h], np.int64)
+    waf.save(HERE + "/acs_synth64_nb26_fixed64.waf", out)
+    print("synth64 nb26", a["best_L"], a["tr_steps"], a["tr_finite"])
+
+
 def main():
     assert O.have_ref(), "build oracle/_ref first: make -C oracle"
     if len(sys.argv) > 1 and sys.argv[1] == "bspline":      # regenerate only the trajectory fixtures
         gen_bspline()
         gen_smooth()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "nb26":
+        gen_nb26()
         return
     for f in ("cubic.stl", "simplified_piece.stl"):
         shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))
@@ -190,6 +222,7 @@ def main():
     # ---- BS_Basic trajectory smoothing ------------------------------------------
     gen_bspline()
     gen_smooth()
+    gen_nb26()
 
 
 if __name__ == "__main__":

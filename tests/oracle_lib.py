@@ -74,6 +74,9 @@ def lib():
         L.wo_acs_create.restype = C.c_void_p
         L.wo_acs_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_float, C.c_float]
+        L.wo_acs_create_nb.restype = C.c_void_p
+        L.wo_acs_create_nb.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_float, C.c_float, C.c_int32]
         L.wo_acs_destroy.argtypes = [C.c_void_p]
         L.wo_acs_reset.argtypes = [C.c_void_p, C.c_float]
         L.wo_acs_solve.restype = C.c_int32
@@ -209,11 +212,12 @@ def write_grid_in(grid, path, lo=None, hi=None):
 
 
 class Acs:
-    def __init__(self, grid, pheromone_0=1.0):
-        self.grid = grid
-        self.h = lib().wo_acs_create(grid.nx, grid.ny, grid.nz, grid.cx.ctypes.data, grid.cy.ctypes.data,
-                                     grid.cz.ctypes.data, grid.free.ctypes.data, C.c_float(grid.precision),
-                                     C.c_float(pheromone_0))
+    def __init__(self, grid, pheromone_0=1.0, nb=6):
+        self.grid, self.nb = grid, nb
+        self.h = lib().wo_acs_create_nb(grid.nx, grid.ny, grid.nz, grid.cx.ctypes.data, grid.cy.ctypes.data,
+                                        grid.cz.ctypes.data, grid.free.ctypes.data, C.c_float(grid.precision),
+                                        C.c_float(pheromone_0), nb)
+        assert self.h, "nb must be 6 or 26"
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -250,7 +254,7 @@ class Acs:
 
     def pheromone(self):
         ptr = lib().wo_acs_pheromone(self.h)
-        return np.ctypeslib.as_array(ptr, shape=(self.grid.n * 6,)).copy()
+        return np.ctypeslib.as_array(ptr, shape=(self.grid.n * self.nb,)).copy()
 
     def last_params(self):
         c, l, q = C.c_int32(), C.c_float(), C.c_float()
@@ -258,7 +262,7 @@ class Acs:
         return c.value, np.float32(l.value), np.float32(q.value)
 
     def heuristic(self, end_id, beta=0.6):
-        out = np.empty(self.grid.n * 6, np.float32)
+        out = np.empty(self.grid.n * self.nb, np.float32)
         lib().wo_acs_heuristic(self.h, end_id, C.c_float(beta), out.ctypes.data)
         return out
 

@@ -136,7 +136,7 @@ def _run_acs_case(tag, grid=None):
     assert sid == waf.scalar(g, "start_id") and eid == waf.scalar(g, "end_id")
     iters, fixed = int(args["iters"]), int(args.get("fixed", 0))
     rng = O.srand(int(args["seed"]))
-    acs = O.Acs(grid)
+    acs = O.Acs(grid, nb=int(args.get("nb", 6)))
     tr = acs.solve(sid, eid, iters, float(np.float32(args["predict"])), fixed_colony=fixed, mode=O.REF, rng=rng)
     ids, ch = acs.best_path()
     assert bits(acs.best_L) == bits(g["best_L"])
@@ -146,7 +146,7 @@ def _run_acs_case(tag, grid=None):
     assert O.rand(rng) == waf.scalar(g, "next_rand")
     ph = acs.pheromone()
     assert O.pher_hash(ph) == waf.scalar(g, "pher_hash") & ((1 << 64) - 1)
-    assert float(np.sum(ph.astype(np.float64))) == pytest.approx(waf.scalar(g, "pher_sum"), rel=1e-12)
+    assert float(np.sum(ph.astype(np.float64))) == pytest.approx(waf.scalar(g, "pher_sum"), rel=1e-9)  # numpy sums pairwise; the hash above is the exact check
     c, lam, q = acs.last_params()
     assert c == waf.scalar(g, "colony_last")
     assert bits(lam) == bits(g["lambda_last"]) and bits(q) == bits(g["Q_last"])
@@ -166,6 +166,24 @@ def _run_acs_case(tag, grid=None):
                                  "acs_piece_fixed128"])
 def test_acs_golden(tag):
     _run_acs_case(tag)
+
+
+# the reference's selectNext / update_pheromone / Agent code on 26-neighbour adjacency lists
+# (built by the harness with the two distances the reference leaves in comments, ACSRank_3D.hpp:380,:383)
+@pytest.mark.parametrize("tag", ["acs_cubic_nb26_adaptive", "acs_cubic_nb26_fixed16", "acs_cubic_nb26_seam",
+                                 "acs_piece_nb26_fixed128"])
+def test_acs_26_neighbour_golden(tag):
+    g, acs = _run_acs_case(tag)
+    if "seam" not in tag:
+        ids, ch = acs.best_path()
+        assert ch.max() > 5 and len(set(ch.tolist())) > 6      # diagonal moves are really taken
+
+
+def test_acs_26_neighbour_synth64_golden():
+    grid = O.synth_grid(64, seed=77, occ_prob=0.10)
+    g = _g("acs_synth64_nb26_fixed64.waf")
+    assert O.fnv1a_bytes(grid.free.tobytes()) == waf.scalar(g, "grid_fnv") & ((1 << 64) - 1)
+    _run_acs_case("acs_synth64_nb26_fixed64", grid=grid)
 
 
 def test_acs_known_answer_ka2():
