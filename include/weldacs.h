@@ -106,6 +106,16 @@ void wa_acs_default_params(wa_acs_params *p);
  * generation, path_capacity the nodes per walk (<= number of voxels). */
 int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                   int64_t path_capacity, wa_acs **out);
+/* Same with an explicit neighbourhood: 6 = face neighbours (what wa_acs_create builds, the reference as
+ * shipped), 26 = faces + edges + corners -- the variant the reference's initFromGridMap walks but stubs
+ * out by setting the two extra distances to 0 (ACSRank_3D.hpp:361-388); here they carry the values the
+ * reference keeps in comments (precision*1.414f, precision*1.732f) and evaporation / reset cover all 26
+ * edges.  Edge index k of a voxel follows the reference's cube loop: offsets z, y, x in {-1,0,1}, z outermost,
+ * centre skipped (k = 0 is (-1,-1,-1), k = 25 is (+1,+1,+1)).  Fields are [N][26]; grids up to 2^27 voxels.
+ * Every other wa_acs_* call is unchanged; wa_acs_read_pheromone then fills nvox*26 floats and
+ * wa_acs_result's `choices` are 0..25. */
+int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                     int64_t path_capacity, int32_t neighbourhood, wa_acs **out);
 void wa_acs_destroy(wa_acs *s);
 /* initFromGridMap :343-408: in-bounds edges pheromone_0, out-of-bounds edges 0. slot<0: all */
 int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float pheromone_0);

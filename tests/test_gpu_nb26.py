@@ -1,0 +1,112 @@
+"""GPU parity for the 26-neighbour search variant (wa_acs_create_nb(..., 26)):
+  REF mode against golden vectors produced by the reference's own selectNext / update_pheromone / Agent
+  code running on 26-neighbour adjacency lists (tests/golden/make_golden.py nb26), bit-exact;
+  DEV mode against the C oracle's 26-neighbour mode, bit-exact (path ids, edge indices, every pheromone value)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_parity import _check_against_golden, _dev_vs_oracle, bits, dgrid_from, ogrid
+from welding_robot_amd import api
+from welding_robot_amd._lib import WeldacsError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("tag", ["acs_cubic_nb26_adaptive", "acs_cubic_nb26_fixed16", "acs_cubic_nb26_seam",
+                                 "acs_piece_nb26_fixed128"])
+def test_nb26_ref_mode_equals_reference_members(ctx, tag):
+    g = _check_against_golden(ctx, tag)
+    if "seam" in tag:
+        assert np.isinf(g["best_L"][0])
+    else:
+        assert g["best_choice"].max() > 5          # diagonal moves in the reference's best path
+
+
+def test_nb26_ref_mode_synth64(ctx):
+    _check_against_golden(ctx, "acs_synth64_nb26_fixed64", og=O.synth_grid(64, seed=77, occ_prob=0.10))
+
+
+def test_nb26_dev_vs_oracle(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    _dev_vs_oracle(ctx, og, sid, eid, 50, 1.03, 16, seed=12345, nb=26)
+    _dev_vs_oracle(ctx, og, sid, eid, 100, 5.0, 0, seed=7, stream=3, nb=26)        # adaptive colony
+    og = ogrid("simplified_piece.stl", "0.0148", 4)
+    _dev_vs_oracle(ctx, og, 2177, 48575, 60, 5.4126, 128, seed=12345, nb=26)
+    og = O.synth_grid(64, seed=77, occ_prob=0.15)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 63, np.float32))
+    _dev_vs_oracle(ctx, og, sid, eid, 25, 300.0, 96, seed=99, nb=26)
+
+
+def test_nb26_more_than_64_depositing_ranks(ctx):
+    og = O.synth_grid(32, seed=5, occ_prob=0.10)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 31, np.float32))
+    _dev_vs_oracle(ctx, og, sid, eid, 8, 100.0, 400, seed=3, nb=26)                 # lambda = 80: two 64-rank chunks
+
+
+def test_nb26_tabu_spill_to_bitmap(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    os.environ["WA_HASH_LOG2"] = "6"
+    try:
+        _dev_vs_oracle(ctx, og, sid, eid, 30, 1.03, 16, seed=5, nb=26)
+        _dev_vs_oracle(ctx, og, sid, eid, 30, 1.03, 16, seed=6, nb=26)
+    finally:
+        del os.environ["WA_HASH_LOG2"]
+
+
+def test_nb26_batch_and_reset(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4)]
+    ids = [og.resolve(og.node_pt(*n)) for n in nodes]
+    pairs = [(i, j) for i in range(4) for j in range(i + 1, 4)]
+    p = api.default_params(max_iteration=40, predict=0.5, rng_mode=api.RNG_DEV, seed=11)
+    sb = api.AcsSolver(ctx, dg, n_slots=len(pairs), max_colony=8, neighbourhood=26)
+    for rep in range(2):                                   # second round: reset_pheromone makes the slots reusable
+        sb.solve(p, [ids[i] for i, _ in pairs], [ids[j] for _, j in pairs], streams=list(range(len(pairs))))
+        for k, (i, j) in enumerate(pairs):
+            a = O.Acs(og, nb=26)
+            if rep:
+                a.reset(1.0)
+            a.solve(ids[i], ids[j], 40, 0.5, mode=O.DEV, seed=11, stream=k)
+            cost, path, ch = sb.result(k)
+            assert bits(cost) == bits(a.best_L)
+            if np.isfinite(cost):
+                assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
+            assert np.array_equal(bits(sb.pheromone(k)), bits(a.pheromone()))
+        sb.reset_pheromone(1.0)
+
+
+def test_nb26_shorter_paths_than_6_neighbours(ctx):
+    """What the variant is for: diagonal moves shorten the path (Euclidean step lengths)."""
+    og = O.synth_grid(48, seed=9, occ_prob=0.05)
+    dg = dgrid_from(ctx, og)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 47, np.float32))
+    out = {}
+    for nb in (6, 26):
+        s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=128, neighbourhood=nb)
+        s.solve(api.default_params(max_iteration=150, predict=150.0, fixed_colony=128, rng_mode=api.RNG_DEV, seed=1), sid, eid)
+        out[nb] = s.result()
+        s.close()
+    assert np.isfinite(out[6][0]) and np.isfinite(out[26][0])
+    assert out[26][0] < out[6][0] and len(out[26][1]) < len(out[6][1])
+
+
+def test_nb_argument_is_checked(ctx):
+    og = O.synth_grid(8, seed=1)
+    dg = dgrid_from(ctx, og)
+    for nb in (0, 7, 18, 27):
+        with pytest.raises(WeldacsError) as e:
+            api.AcsSolver(ctx, dg, neighbourhood=nb)
+        assert e.value.code == 1

@@ -144,10 +144,10 @@ def default_params(**kw):
 
 
 class AcsSolver:
-    def __init__(self, ctx, grid, n_slots=1, max_colony=256, path_capacity=0):
-        self.ctx, self.grid, self.n_slots, self.max_colony = ctx, grid, n_slots, max_colony
+    def __init__(self, ctx, grid, n_slots=1, max_colony=256, path_capacity=0, neighbourhood=6):
+        self.ctx, self.grid, self.n_slots, self.max_colony, self.nb = ctx, grid, n_slots, max_colony, neighbourhood
         h = C.c_void_p()
-        ctx.check(ctx.lib.wa_acs_create(ctx.h, grid.h, n_slots, max_colony, path_capacity, C.byref(h)))
+        ctx.check(ctx.lib.wa_acs_create_nb(ctx.h, grid.h, n_slots, max_colony, path_capacity, neighbourhood, C.byref(h)))
         self.h = h
         self.iters = 0
         ctx._children.add(self)
@@ -221,7 +221,7 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_export_trace(self.h, dst_device_ptr, gen0, count))
 
     def pheromone(self, slot=0):
-        out = np.empty(self.grid.n * 6, np.float32)
+        out = np.empty(self.grid.n * self.nb, np.float32)
         self.ctx.check(self.ctx.lib.wa_acs_read_pheromone(self.h, slot, _ptr(out)))
         return out
 

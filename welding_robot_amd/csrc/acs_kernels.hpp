@@ -43,7 +43,13 @@ struct WaAcsDev {
     int64_t vbits_words;
     int32_t max_colony;
     int32_t trace_cap;
+    int32_t nb;                    // edges per voxel: 6 (face neighbours) or 26 (faces + edges + corners)
 };
+
+// path word = voxel id | (edge index taken to arrive << SHIFT)
+template <int NB> struct WaNbT;
+template <> struct WaNbT<6> { static constexpr int SHIFT = WA_K_SHIFT; static constexpr int32_t IDM = (int32_t)WA_ID_MASK; };
+template <> struct WaNbT<26> { static constexpr int SHIFT = 27; static constexpr int32_t IDM = (1 << 27) - 1; };
 
 __device__ __forceinline__ int32_t wa_delta(int k, int32_t nx, int32_t nxy)
 {
@@ -604,6 +610,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 // visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i (bits
 // precomputed by wa_best_prefix_tabu whenever the best path changes).
 // Output per node: thr[k] = admissible ? prob_sum_k : -inf (k = 0..5), total, edge taken to best[i+1].
+template <int NB>
 __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
                                               bool skip_best_src, float *s_dep);
 
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
         return;
     }
     const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..511: (bx = ab & 7, rank bit = ab >> 3)
-    wa_apply_body(D, slot, 0, ab >> 3, ab & 7, 8, true, s_dep);
+    wa_apply_body<6>(D, slot, 0, ab >> 3, ab & 7, 8, true, s_dep);
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
@@ -875,6 +882,7 @@ __device__ __forceinline__ void wa_best_prefix_tabu(const WaAcsDev &D, int32_t s
 // The (L, ant) sort keys are staged in LDS (up to WA_RANK_LDS ants) so the counting rank reads
 // broadcast LDS words instead of a dependent chain of global loads.
 #define WA_RANK_LDS 2048
+template <int NB>
 __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 {
     const int32_t slot = blockIdx.x, tid = threadIdx.x;
@@ -936,10 +944,10 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
         for (int32_t i = tid; i < blen; i += blockDim.x) {
             int32_t w = src[i];
             dst[i] = w;
-            mark[w & WA_ID_MASK] = ver;
-            pos[w & WA_ID_MASK] = i;
+            mark[w & WaNbT<NB>::IDM] = ver;
+            pos[w & WaNbT<NB>::IDM] = i;
         }
-        wa_best_prefix_tabu(D, slot, blen, ver);
+        if (NB == 6) wa_best_prefix_tabu(D, slot, blen, ver);   // replay support exists for the 6-neighbour walk only
         bestL = iterL;
         if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; }
     }
@@ -1144,8 +1152,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += 8 * blockDim.x) {
         int32_t w = path[i];
-        int32_t v = path[i - 1] & WA_ID_MASK;
-        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        int32_t v = path[i - 1] & WaNbT<6>::IDM;
+        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WaNbT<6>::SHIFT);
         atomicOr(&mask[e], 1ULL << bit);
     }
 }
@@ -1190,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_evaporate(const float *src_base, float 
 // a per-edge rank mask; pass 2 lets the LOWEST rank present on an edge own it and apply all
 // present ranks in ascending order (= the reference's order), then clear the mask.
 // grid = (blocks, 64 ranks, n_problems)
+template <int NB>
 __global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
 {
     const int32_t slot = blockIdx.z, bit = blockIdx.y, o = base + bit + 1;
@@ -1201,13 +1210,14 @@ __global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     for (int32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         int32_t w = path[i];
-        int32_t v = path[i - 1] & WA_ID_MASK;
-        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        int32_t v = path[i - 1] & WaNbT<NB>::IDM;
+        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
         atomicOr(&mask[e], 1ULL << bit);
     }
 }
 // Body of the apply pass for rank bit `bit` of chunk `base`, x-block `bx` of `nbx`.  skip_best_src: edges that
 // leave a best-path node belong to the replay-table rows of the same launch (k_apply_table).
+template <int NB>
 __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
                                               bool skip_best_src, float *s_dep)
 {
@@ -1227,13 +1237,13 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
     const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
     for (int32_t i = 1 + bx * blockDim.x + threadIdx.x; i < len; i += nbx * blockDim.x) {
         int32_t w = path[i];
-        int32_t v = path[i - 1] & WA_ID_MASK;
+        int32_t v = path[i - 1] & WaNbT<NB>::IDM;
         const bool v_best = mark[v] == ver;
         if (skip_best_src && v_best) continue;
-        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WA_K_SHIFT);
+        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
         unsigned long long m = mask[e];
         if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
-        bool onbest = v_best && mark[w & WA_ID_MASK] == ver;          // :209
+        bool onbest = v_best && mark[w & WaNbT<NB>::IDM] == ver;      // :209
         const float bonus = (float)onbest * lambda * Q / bestL;       // second term of :211, the same for every rank
         float p = pher[e];
         while (m) {
@@ -1246,8 +1256,211 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
     }
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
 {
     __shared__ float s_dep_[64];
-    wa_apply_body(D, blockIdx.z, base, blockIdx.y, blockIdx.x, gridDim.x, false, s_dep_);
+    wa_apply_body<NB>(D, blockIdx.z, base, blockIdx.y, blockIdx.x, gridDim.x, false, s_dep_);
+}
+
+// =====================================================================================================
+// 26-neighbour variant (ACSRank_3D.hpp:352-388 with the two distances the reference keeps
+// in comments restored: edge neighbours precision*1.414f, corner neighbours precision*1.732f).
+// Edge order = the reference's cube loop: z offset outermost, then y, then x, centre skipped.
+// Same selectNext, same ranking, same deposit; pheromone / heuristic / rank-mask fields are [N][26].
+// One wavefront per ant, lane k < 26 owns neighbour k.  This is the plain loop (LDS hash tabu with
+// bitmap spill, ordered sums by broadcast), without the 6-neighbour path's prefetching and replay.
+// =====================================================================================================
+__device__ __forceinline__ void wa_off26(int k, int &dx, int &dy, int &dz)
+{
+    const int q = k < 13 ? k : k + 1;
+    dz = q / 9 - 1;
+    dy = (q / 3) % 3 - 1;
+    dx = q % 3 - 1;
+}
+
+// thread per (voxel, edge): coalesced 4-B stores over the [N][26] field
+__global__ __launch_bounds__(256) void k_init_pheromone26(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= D.d.n * 26) return;
+    const int32_t slot = slot0 + blockIdx.y;
+    const int64_t id = t / 26;
+    const int k = (int)(t - id * 26);
+    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    int dx, dy, dz;
+    wa_off26(k, dx, dy, dz);
+    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+    const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
+    const bool adm = inb && D.occ[id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
+    const float v = (inb || mode == 1) ? p0 : 0.f;
+    D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
+}
+
+__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= D.d.n * 26) return;
+    const int32_t slot = blockIdx.y;
+    const int64_t id = t / 26;
+    const int k = (int)(t - id * 26);
+    const int32_t end = D.ctl[slot].end;
+    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
+    int dx, dy, dz;
+    wa_off26(k, dx, dy, dz);
+    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+    float out = 0.f;
+    if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+        const float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
+        const float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];     // :151
+        const float dot = ax * bx + ay * by + az * bz;
+        const float na = sqrtf(ax * ax + ay * ay + az * az);
+        const float nb = sqrtf(bx * bx + by * by + bz * bz);
+        out = 1 + beta * (dot / (na * nb));                                                      // :152-154
+    }
+    D.heur[(int64_t)slot * D.pher_stride + t] = out;
+}
+
+template <int MODE>
+__device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant, int32_t start,
+                                              int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t *rng_r,
+                                              int32_t &rng_f, int32_t &rng_b, int32_t *flags_out)
+{
+    const int lane = threadIdx.x;
+    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    WaTabu T;
+    T.tab = tab;
+    T.mask = (1u << hash_log2) - 1u;
+    T.shift = 32 - hash_log2;
+    T.bits = D.vbits + ((int64_t)slot * D.max_colony + ant) * D.vbits_words;
+    T.spilled = false;
+    const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
+    int4 *tab4 = reinterpret_cast<int4 *>(tab);
+    for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        tabu_insert(T, start);  // addStartNode :81-86
+        path[0] = start;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane constants: neighbour offset, in-bounds test inputs, step length by move type (:369-385)
+    const int k = lane < 26 ? lane : 25;
+    int dx, dy, dz;
+    wa_off26(k, dx, dy, dz);
+    const int32_t dk = dz * D.d.nxy + dy * D.d.nx + dx;
+    const float d1 = R.precision, d2 = R.precision * 1.414f, d3 = R.precision * 1.732f;
+    int32_t cur = start, len = 1;
+    uint32_t step = 0;
+    float L = 0.f;
+    for (;;) {
+        if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
+            __threadfence();
+            for (int i = lane; i < len; i += 64) {
+                int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WaNbT<26>::IDM;
+                uint32_t old = atomicOr(&T.bits[(uint32_t)id >> 5], 1u << (id & 31));
+                asm volatile("" ::"v"(old));
+            }
+            __threadfence();
+            T.spilled = true;
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_BITMAP_USED);
+        }
+        float p = -0.f, h = 0.f;
+        bool adm = false;
+        if (lane < 26) {
+            p = pher[(int64_t)cur * 26 + lane];
+            h = heur[(int64_t)cur * 26 + lane];
+            if ((__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);   // sign bit: out of bounds or occupied
+        }
+        const float info = wa_powi(fabsf(p), R.alpha) * h;                        // :154
+        const uint32_t m = (uint32_t)__ballot(adm) & 0x3ffffffu;
+        if (m == 0) { L = INFINITY; break; }                                      // :162-166
+        float total = 0.f;
+#pragma unroll
+        for (int i = 0; i < 26; i++) {                                            // :155, ascending edge order
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
+            if ((m >> i) & 1u) total += v;
+        }
+        int32_t r;
+        if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
+        else r = wa_glibc_next(rng_r, rng_f, rng_b);
+        float rnd = (float)r / 2147483648.0f;                                     // :169
+        rnd *= total;
+        float prob = 0.f;
+        int pick = -1;
+#pragma unroll
+        for (int i = 25; i >= 0; i--) {                                           // :172-189, descending edge order
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
+            if (pick < 0 && ((m >> i) & 1u)) {
+                prob += v;
+                if (prob >= rnd) pick = i;
+            }
+        }
+        if (pick < 0) { L = INFINITY; break; }                                    // :191-192
+        int px, py, pz;
+        wa_off26(pick, px, py, pz);
+        const int32_t next = cur + pz * D.d.nxy + py * D.d.nx + px;
+        if (len >= D.path_cap) {
+            if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+            L = INFINITY;
+            break;
+        }
+        if (lane == 0) {
+            path[len] = next | (pick << WaNbT<26>::SHIFT);
+            tabu_insert(T, next);
+        }
+        __builtin_amdgcn_wave_barrier();
+        len++;
+        const int type = (px != 0) + (py != 0) + (pz != 0);
+        L += type == 1 ? d1 : type == 2 ? d2 : d3;                                // :78
+        step++;
+        if (next == end) break;
+        cur = next;
+    }
+    if (T.spilled) {  // leave the bitmap all-zero for the next walk
+        __threadfence();
+        for (int i = lane; i < len; i += 64) {
+            int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WaNbT<26>::IDM;
+            __hip_atomic_store(&T.bits[(uint32_t)id >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+    }
+    if (lane == 0) {
+        D.antL[(int64_t)slot * D.max_colony + ant] = L;
+        D.antLen[(int64_t)slot * D.max_colony + ant] = len;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
+{
+    extern __shared__ int32_t lds[];
+    const int32_t slot = blockIdx.y, ant = blockIdx.x;
+    const WaSlotCtl *c = &D.ctl[slot];
+    const int32_t colony = c->colony[gen & 1];
+    if (ant >= colony || colony > D.max_colony) return;
+    const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
+    int32_t f = 0, b = 0;
+    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+}
+
+__global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
+{
+    extern __shared__ int32_t lds[];
+    const int32_t slot = blockIdx.y;
+    const WaSlotCtl *c = &D.ctl[slot];
+    const int32_t colony = c->colony[gen & 1];
+    if (colony > D.max_colony) return;
+    int32_t r[31];
+    for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
+    int32_t f = D.rng->f, b = D.rng->b;
+    const int32_t start = c->start, end = c->end;
+    for (int32_t ant = 0; ant < colony; ant++)
+        wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
+        D.rng->f = f;
+        D.rng->b = b;
+    }
 }

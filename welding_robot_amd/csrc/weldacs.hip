@@ -52,7 +52,7 @@ struct EvPair { hipEvent_t a, b; int cls; };
 struct wa_acs {
     wa_ctx *ctx;
     const wa_grid *grid;
-    int32_t n_slots, max_colony, n_active;
+    int32_t n_slots, max_colony, n_active, nb;
     int64_t path_cap;
     WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
@@ -353,8 +353,8 @@ static int env_int(const char *name, int def)
     return v && *v ? atoi(v) : def;
 }
 
-int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
-                  int64_t path_capacity, wa_acs **out)
+static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                      int64_t path_capacity, int32_t nb, wa_acs **out)
 {
     if (!ctx || !grid || !out || n_slots < 1 || max_colony < 1) return fail(ctx, WA_ERR_ARG, "wa_acs_create: bad argument");
     *out = nullptr;
@@ -375,9 +375,15 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     s->cur_buf = 0;
     for (int i = 0; i < WA_K_COUNT; i++) { s->prof_ms[i] = 0; s->prof_n[i] = 0; }
     const int64_t n = grid->d.n;
-    if (24 * n >= (int64_t)1 << 31) {  // the walk addresses a slot's pheromone field with signed 32-bit byte offsets
+    if (nb != 6 && nb != 26) { delete s; return fail(ctx, WA_ERR_ARG, "wa_acs_create: neighbourhood must be 6 or 26"); }
+    s->nb = nb;
+    if (nb == 6 && 24 * n >= (int64_t)1 << 31) {  // the walk addresses a slot's pheromone field with signed 32-bit byte offsets
         delete s;
         return fail(ctx, WA_ERR_ARG, "wa_acs_create: grids above 89,478,485 voxels (~447^3) are not supported");
+    }
+    if (nb == 26 && n > (int64_t)WaNbT<26>::IDM) {  // path word = 27-bit voxel id + 5-bit edge index
+        delete s;
+        return fail(ctx, WA_ERR_ARG, "wa_acs_create: 26-neighbour grids above 2^27 voxels (512^3) are not supported");
     }
     if (path_capacity <= 0) path_capacity = n < (1 << 18) ? n : (1 << 18);
     if (path_capacity > n) path_capacity = n;
@@ -386,7 +392,8 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     WaAcsDev &D = s->D;
     D.d = grid->d;
     D.cx = grid->cx; D.cy = grid->cy; D.cz = grid->cz; D.occ = grid->occ;
-    D.pher_stride = ((6 * n + 63) / 64) * 64;
+    D.nb = nb;
+    D.pher_stride = (((int64_t)nb * n + 63) / 64) * 64;
     D.path_cap = path_capacity;
     D.vbits_words = (n + 31) / 32;
     D.max_colony = max_colony;
@@ -412,7 +419,7 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
     e = e ? e : dalloc(&D.bestpos, S * n);
     e = e ? e : dalloc(&D.besttabu, S * path_capacity);
-    if (env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8 + 256);  // + slack: the replay reads whole 16-node chunks
+    if (nb == 6 && env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8 + 256);  // + slack: the replay reads whole 16-node chunks
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
     e = e ? e : dalloc(&D.antLen, S * C);
@@ -450,6 +457,17 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
     return WA_OK;
 }
 
+int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity,
+                  wa_acs **out)
+{
+    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, 6, out);
+}
+int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity,
+                     int32_t neighbourhood, wa_acs **out)
+{
+    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, neighbourhood, out);
+}
+
 static void free_trace(wa_acs *s)
 {
     hipFree(s->D.trBest); hipFree(s->D.trIter); hipFree(s->D.trColony); hipFree(s->D.trFinite); hipFree(s->D.trSteps);
@@ -478,6 +496,12 @@ static int init_pher(wa_acs *s, int32_t slot, float p0, int mode)
 {
     if (!s || slot >= s->n_slots || !(p0 >= 0)) return fail(s ? s->ctx : nullptr, WA_ERR_ARG, "pheromone init: bad argument");
     int32_t slot0 = slot < 0 ? 0 : slot, cnt = slot < 0 ? s->n_slots : 1;
+    if (s->nb == 26) {
+        dim3 grid26((unsigned)((s->D.d.n * 26 + 255) / 256), (unsigned)cnt);
+        k_init_pheromone26<<<grid26, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
+        HIPC(s->ctx, hipGetLastError());
+        return WA_OK;
+    }
     dim3 grid((unsigned)((s->D.d.n + 255) / 256), (unsigned)cnt);
     k_init_pheromone<<<grid, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
     HIPC(s->ctx, hipGetLastError());
@@ -554,8 +578,13 @@ int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
     HIPC(ctx, hipMemcpyAsync(s->d_ends, he.data(), sizeof(long long) * n_problems, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(s->d_streams, hst.data(), sizeof(uint32_t) * n_problems, hipMemcpyHostToDevice, ctx->stream));
     k_begin<<<(n_problems + 63) / 64, 64, 0, ctx->stream>>>(s->D, R, n_problems, s->d_starts, s->d_ends, s->d_streams);
-    dim3 hg((unsigned)((s->D.d.n + 255) / 256), (unsigned)n_problems);
-    k_heuristic<<<hg, 256, 0, ctx->stream>>>(s->D, R.beta);
+    if (s->nb == 26) {
+        dim3 hg26((unsigned)((s->D.d.n * 26 + 255) / 256), (unsigned)n_problems);
+        k_heuristic26<<<hg26, 256, 0, ctx->stream>>>(s->D, R.beta);
+    } else {
+        dim3 hg((unsigned)((s->D.d.n + 255) / 256), (unsigned)n_problems);
+        k_heuristic<<<hg, 256, 0, ctx->stream>>>(s->D, R.beta);
+    }
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
     s->n_active = n_problems;
@@ -592,14 +621,14 @@ static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float 
         p.cls = WA_K_EVAPORATE;
         if (hipEventCreate(&p.a) == hipSuccess) {
             if (hipEventCreate(&p.b) == hipSuccess) {
-                hipExtLaunchKernelGGL(k_evaporate, grid, dim3(256), 0, st, p.a, p.b, 0, sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
+                hipExtLaunchKernelGGL(k_evaporate, grid, dim3(256), 0, st, p.a, p.b, 0, sp, dp, s->D.pher_stride, (int64_t)s->nb * s->D.d.n, rho);
                 s->ev.push_back(p);
                 return;
             }
             hipEventDestroy(p.a);
         }
     }
-    k_evaporate<<<grid, 256, 0, st>>>(sp, dp, s->D.pher_stride, 6 * s->D.d.n, rho);
+    k_evaporate<<<grid, 256, 0, st>>>(sp, dp, s->D.pher_stride, (int64_t)s->nb * s->D.d.n, rho);
 }
 
 // the fused post-walk launch (sweep + rank + mark), timed per dispatch when sampled
@@ -639,19 +668,25 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     const size_t shmem = sizeof(int32_t) << s->hash_log2;
     const int32_t dep_bound = (int32_t)(0.2 * s->colony_bound) + 1;
     const int32_t chunks = (dep_bound + 63) / 64;
-    const bool fused = s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
+    const bool fused = s->nb == 6 && s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
                        !s->overlap_walk && !s->overlap_rank;
     for (int32_t g = 0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
         const int32_t gen = s->gens_enqueued;  // == the device-side generation counter since wa_acs_begin
         float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (s->inplace ? 0 : 1)];
-        if (s->overlap_walk) {  // fork the sweep before the walk
+        if (s->overlap_walk && s->nb == 6) {  // fork the sweep before the walk
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             launch_evaporate(s, ctx->stream2, src, dst, 0, P, s->R.rho, sampled);
         }
         EvPair *e = prof_open(s, WA_K_WALK, sampled);
-        if (s->R.rng_mode == WA_RNG_DEV) {
+        if (s->nb == 26) {
+            if (s->R.rng_mode == WA_RNG_DEV) {
+                if (s->colony_bound > 0) k_walk_dev26<<<dim3((unsigned)s->colony_bound, (unsigned)P), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
+            } else {
+                k_walk_ref26<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
+            }
+        } else if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
                 dim3 wg((unsigned)s->colony_bound, (unsigned)P);
                 if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
@@ -669,29 +704,30 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
             if (s->D.rtab && s->fuse_table) {
                 k_apply_table<<<dim3(WA_TABLE_BLOCKS + 512, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
             } else {
-                k_deposit_apply<<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
+                k_deposit_apply<6><<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
                 if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
             }
             prof_close(s, e);
             s->gens_enqueued++;
             continue;
         }
-        if (s->overlap_walk) {  // rank on the main stream, join the early sweep
+        if (s->overlap_walk && s->nb == 6) {  // rank on the main stream, join the early sweep
             e = prof_open(s, WA_K_RANK, sampled);
-            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
+            k_rank<6><<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
             prof_close(s, e);
             HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        } else if (s->overlap_rank) {  // rank on stream2 || sweep on the main stream
+        } else if (s->overlap_rank && s->nb == 6) {  // rank on stream2 || sweep on the main stream
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPC(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            k_rank<<<P, 256, 0, ctx->stream2>>>(s->D, s->R, gen);
+            k_rank<6><<<P, 256, 0, ctx->stream2>>>(s->D, s->R, gen);
             HIPC(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
             HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         } else {  // fully serial
             e = prof_open(s, WA_K_RANK, sampled);
-            k_rank<<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
+            if (s->nb == 26) k_rank<26><<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
+            else k_rank<6><<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
             prof_close(s, e);
             launch_evaporate(s, ctx->stream, src, dst, 0, P, s->R.rho, sampled);
         }
@@ -700,8 +736,13 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         e = prof_open(s, WA_K_DEPOSIT, sampled);
         for (int32_t c = 0; c < chunks; c++) {
             dim3 dg(8, 64, (unsigned)P);
-            k_deposit_mark<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
-            k_deposit_apply<<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+            if (s->nb == 26) {
+                k_deposit_mark<26><<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+                k_deposit_apply<26><<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+            } else {
+                k_deposit_mark<6><<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+                k_deposit_apply<6><<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
+            }
         }
         if (s->D.rtab && s->R.rng_mode == WA_RNG_DEV) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
         prof_close(s, e);
@@ -762,8 +803,10 @@ int wa_acs_result(wa_acs *s, int32_t slot, float *cost, int64_t *len, int32_t *p
         std::vector<int32_t> w(n);
         HIPC(ctx, hipMemcpy(w.data(), s->D.bestpath + (int64_t)slot * s->D.path_cap, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < n; i++) {
-            if (path_ids) path_ids[i] = w[i] & (int32_t)WA_ID_MASK;
-            if (choices && i > 0) choices[i - 1] = (int8_t)((uint32_t)w[i] >> WA_K_SHIFT);
+            const int32_t idm = s->nb == 26 ? WaNbT<26>::IDM : WaNbT<6>::IDM;
+            const int sh = s->nb == 26 ? WaNbT<26>::SHIFT : WaNbT<6>::SHIFT;
+            if (path_ids) path_ids[i] = w[i] & idm;
+            if (choices && i > 0) choices[i - 1] = (int8_t)((uint32_t)w[i] >> sh);
         }
     }
     return WA_OK;
@@ -804,7 +847,7 @@ int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out)
     if (!s || !out || slot < 0 || slot >= s->n_slots) return WA_ERR_ARG;
     wa_ctx *ctx = s->ctx;
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t m = 6 * s->D.d.n;
+    const int64_t m = (int64_t)s->nb * s->D.d.n;
     HIPC(ctx, hipMemcpy(out, s->D.pher + (int64_t)slot * s->D.pher_stride, sizeof(float) * m, hipMemcpyDeviceToHost));
     uint32_t *u = (uint32_t *)out;
     for (int64_t i = 0; i < m; i++) u[i] &= 0x7fffffffu;  // drop the admissibility bit
