@@ -26,10 +26,10 @@ for nb in (6, 26):
     sweep_s = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1) * 1e-3
     sweep_bytes = 8 * nb * N ** 3
     print("nb=%2d: %d generations in %.1f ms = %.0f gen/s (per-dispatch events on: %s); sweep %.0f MB -> %.2f TB/s; best cost %.4f in %d nodes, "
-          "first generation with that cost %d, steps/ant gen0 %.0f" % (
+          "first generation with that cost %d, steps/ant gen0 %.0f, mean %.0f" % (
               nb, GENS, (t1 - t0) * 1e3, GENS / (t1 - t0), per, sweep_bytes / 1e6,
               sweep_bytes / sweep_s / 1e12, cost, len(path),
-              int(np.argmax(tr["bestL"] == tr["bestL"][-1])), tr["steps"][0] / ANTS))
+              int(np.argmax(tr["bestL"] == tr["bestL"][-1])), tr["steps"][0] / ANTS, tr["steps"].mean() / ANTS))
     if nb == 26:
         a = O.Acs(og, nb=26)
         g = 4

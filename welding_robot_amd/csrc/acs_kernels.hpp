@@ -188,6 +188,16 @@ __device__ __forceinline__ float dpp_from_above(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));
 }
 
+// whole-wave versions (wave_shr:1 / wave_shl:1, GFX9 DPP): lane i <- lane i-1 / lane i+1 across all 64 lanes
+__device__ __forceinline__ float dpp_wave_from_below(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_wave_from_above(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+}
+
 // In-kernel stamps (diagnostic builds only, -DWA_STAMPS): s_memtime at section boundaries of the
 // walk's inner loop, differences summed per section; ant 0 of slot 0 writes the sums to D.dbg.
 // Never enabled in the product build (cdna_hip_programming.md 7, "In-kernel stamps").
@@ -1355,6 +1365,8 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     int32_t cur = start, len = 1;
     uint32_t step = 0;
     float L = 0.f;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+    const int64_t last_rec = (D.d.n - 1) * 26;
     for (;;) {
         if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
             __threadfence();
@@ -1372,32 +1384,30 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         if (lane < 26) {
             p = pher[(int64_t)cur * 26 + lane];
             h = heur[(int64_t)cur * 26 + lane];
-            if ((__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);   // sign bit: out of bounds or occupied
         }
+        asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(w3));   // last step's cache-warming loads retire before these
+        if (lane < 26 && (__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);   // sign bit: out of bounds or occupied
         const float info = wa_powi(fabsf(p), R.alpha) * h;                        // :154
-        const uint32_t m = (uint32_t)__ballot(adm) & 0x3ffffffu;
-        if (m == 0) { L = INFINITY; break; }                                      // :162-166
-        float total = 0.f;
+        const unsigned long long mb = __ballot(adm);
+        if (mb == 0) { L = INFINITY; break; }                                     // :162-166
+        // the two ORDERED sums of selectNext as whole-wave DPP chains over the zero-padded candidates:
+        // t: lane i <- lane i-1, after 25 steps lane 25 holds (((0+a0)+a1)+...)+a25            (:155)
+        // c: lane i <- lane i+1, after 25 steps lane i holds prob_sum once candidates 25..i are in (:172-177)
+        const float a = adm ? info : 0.f;
+        float t = 0.f + a, c = 0.f + a;
 #pragma unroll
-        for (int i = 0; i < 26; i++) {                                            // :155, ascending edge order
-            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
-            if ((m >> i) & 1u) total += v;
+        for (int i = 0; i < 25; i++) {
+            t = dpp_wave_from_below(t) + a;
+            c = dpp_wave_from_above(c) + a;
         }
+        const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 25));
         int32_t r;
         if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
         else r = wa_glibc_next(rng_r, rng_f, rng_b);
         float rnd = (float)r / 2147483648.0f;                                     // :169
         rnd *= total;
-        float prob = 0.f;
-        int pick = -1;
-#pragma unroll
-        for (int i = 25; i >= 0; i--) {                                           // :172-189, descending edge order
-            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(info), i));
-            if (pick < 0 && ((m >> i) & 1u)) {
-                prob += v;
-                if (prob >= rnd) pick = i;
-            }
-        }
+        const unsigned long long hit = __ballot(adm && c >= rnd);                 // first hit in descending edge order
+        const int pick = hit ? 63 - __clzll((long long)hit) : -1;
         if (pick < 0) { L = INFINITY; break; }                                    // :191-192
         int px, py, pz;
         wa_off26(pick, px, py, pz);
@@ -1418,7 +1428,15 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         step++;
         if (next == end) break;
         cur = next;
+        {   // the records the NEXT step may need are those of cur's 26 neighbours: lane k touches both ends of
+            // neighbour k's 104-byte pheromone and heuristic records so that step's loads hit in cache
+            int64_t rec = ((int64_t)cur + dk) * 26;
+            rec = rec < 0 ? 0 : rec > last_rec ? last_rec : rec;
+            w0 = pher[rec]; w1 = pher[rec + 25];
+            w2 = heur[rec]; w3 = heur[rec + 25];
+        }
     }
+    asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(w3));
     if (T.spilled) {  // leave the bitmap all-zero for the next walk
         __threadfence();
         for (int i = lane; i < len; i += 64) {
