@@ -485,58 +485,43 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
 // edge the ant rebuilds its tabu hash from the prefix and continues in the general loop, which
 // recomputes that step in full.  After convergence nearly every step of every ant is a replay step.
 // Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).
-__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, float *lds_t, int32_t lds_floats, int32_t rlen,
-                                              uint64_t antkey, int32_t &node)
+__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node)
 {
-    // Replay steps do not depend on each other while the ant stays on the path, so 8 consecutive
-    // nodes are checked at once: chunk c = T[8c .. 8c+7][8] has node 8c+g in lane group g; every
-    // group forms its own draw (a pure function of the step number = node index), its own
-    // rnd = u * total, and asks "would this ant NOT take the path's edge here?".  The first set bit
-    // of that ballot is the first node where the ant leaves the path (or dies).
-    // The table (32 B per node) is first staged into the LDS the tabu hash will use later -- all
-    // its loads in flight at once -- so the chunk loop reads LDS instead of paying one global
-    // round trip per 8 nodes; paths longer than the staging area stream from global memory.
+    // Replay steps do not depend on each other while the ant stays on the path, so 64 consecutive nodes
+    // are checked at once, ONE LANE PER NODE: the lane reads its node's 32-byte row (two coalesced 16-B
+    // loads straight from the table, the next 64 rows already in flight), forms its own draw (a pure
+    // function of the step number = node index), rnd = u * total, and finds the edge the roulette would
+    // take: scanning i = 5..0 the first thr[i] >= rnd is the highest set bit of the 6 comparisons.
+    // The first lane whose edge is not the path's edge is the first node where the ant leaves the path
+    // (some edge taken) or dies (none).
     const int lane = threadIdx.x;
-    const int role = lane & 7;
-    const bool thr_lane = role < 6;
-    const int tot_src = (lane & 0x38) | 6, nk_src = (lane & 0x38) | 7;
-    const int32_t n_floats = rlen * 8;
-    const bool staged = n_floats <= lds_floats;
-    if (staged) {
-        for (int32_t q = lane; q < n_floats; q += 64) lds_t[q] = T[q];
-        __builtin_amdgcn_wave_barrier();
-    }
-    const float *src = staged ? lds_t : T;
-    // one 8-node chunk: returns the ballot of lanes that would NOT follow the path (0 = all 8 nodes follow)
-    auto check = [&](float tv, int32_t base, unsigned long long &hit_mask) -> unsigned long long {
-        const int32_t nodev = base + (lane >> 3);
-        const bool valid = thr_lane && nodev < rlen - 1;  // decisions exist at nodes 0 .. rlen-2
-        float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
-        const float total = __shfl(tv, tot_src);
-        const int nk = __float_as_int(__shfl(tv, nk_src));
-        rnd *= total;                                      // :170
-        const bool hit = valid && tv >= rnd;               // thr = admissible ? prob_sum : -inf   (:178)
-        // scanning i = 5..0 the first hit must be the path's edge nk: a hit above nk deviates, no hit at nk
-        // means either a lower edge is taken or nothing is (dead end)
-        const bool fail = valid && ((hit && role > nk) || (role == nk && !hit));
-        hit_mask = __ballot(hit);
-        return __ballot(fail);
-    };
-    // two independent chunks per iteration so that their LDS reads, shuffles and draws overlap
-    for (int32_t i0 = 0;; i0 += 16) {
-        const float ta = src[(i0 >> 3) * 64 + lane];  // (entries past rlen are never used: `valid` masks them;
-        const float tb = i0 + 8 < rlen ? src[((i0 >> 3) + 1) * 64 + lane] : 0.f;  //  the staging area / table is large enough)
-        unsigned long long ha, hb;
-        const unsigned long long fa = check(ta, i0, ha);
-        const unsigned long long fb = check(tb, i0 + 8, hb);
-        if (__builtin_expect((fa | fb) != 0, 0)) {
-            const bool in_a = fa != 0;
-            const unsigned long long fm = in_a ? fa : fb, hm = in_a ? ha : hb;
-            const int g = (__ffsll((long long)fm) - 1) >> 3;
-            node = i0 + (in_a ? 0 : 8) + g;
-            return ((hm >> (8 * g)) & 0x3fULL) ? 3 : 1;
+    const float4 *__restrict__ T4 = reinterpret_cast<const float4 *>(T);
+    const int32_t last = rlen - 1;                      // decisions exist at nodes 0 .. rlen-2
+    int32_t nv = lane < last ? lane : last - 1;         // (rlen >= 2; masked lanes re-read a valid row)
+    float4 a = T4[2 * nv], b = T4[2 * nv + 1];
+    for (int32_t i0 = 0;; i0 += 64) {
+        const int32_t nodev = i0 + lane;
+        const bool valid = nodev < last;
+        const float4 ca = a, cb = b;
+        if (i0 + 64 < last) {                           // rows of the next 64 nodes
+            nv = nodev + 64 < last ? nodev + 64 : last - 1;
+            a = T4[2 * nv];
+            b = T4[2 * nv + 1];
         }
-        if (i0 + 16 >= rlen - 1) { node = rlen - 1; return 2; }  // every decision up to the last node followed the path
+        float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
+        rnd *= cb.z;                                                               // :170, total
+        const int nk = __float_as_int(cb.w);
+        // thr = admissible ? prob_sum : -inf   (:178)
+        const uint32_t h = (ca.x >= rnd ? 1u : 0u) | (ca.y >= rnd ? 2u : 0u) | (ca.z >= rnd ? 4u : 0u) | (ca.w >= rnd ? 8u : 0u) |
+                           (cb.x >= rnd ? 16u : 0u) | (cb.y >= rnd ? 32u : 0u);
+        const int pick = h ? 31 - __clz((int)h) : -1;
+        const unsigned long long fm = __ballot(valid && pick != nk);
+        if (__builtin_expect(fm != 0, 0)) {
+            const int g = __ffsll((long long)fm) - 1;
+            node = i0 + g;
+            return __builtin_amdgcn_readlane((int)h, g) ? 3 : 1;
+        }
+        if (i0 + 64 >= last) { node = last; return 2; }  // every decision up to the last node followed the path
     }
 }
 
@@ -556,8 +541,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     const int32_t *prefix_words = nullptr;
     if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
-        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, reinterpret_cast<float *>(tab), 1 << hash_log2, rlen,
-                                        antkey, node);
+        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
         st.len = node + 1;
         for (int32_t q = lane; q < st.len; q += 64) path[q] = bpath[q];  // the walked prefix IS the best path's
         if (what != 3) {  // finished on the replay track
@@ -1021,6 +1005,49 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
     }
 }
 
+// ------------------------------------------------------------------ the evaporation sweep body
+// :268-272 -- dst = src * rho over n_floats values; float4 per lane, 4 independent float4 in flight per
+// thread, grid-stride over E blocks.  One definition for k_evaporate and the fused k_evap_rank_mark.
+// WA_NT_LOAD / WA_NT_STORE (experiment builds): non-temporal hints on the stream.
+typedef float wa_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p)
+{
+#ifdef WA_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v)
+{
+#ifdef WA_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
+{
+    const wa_v4f *s4 = reinterpret_cast<const wa_v4f *>(src);
+    wa_v4f *d4 = reinterpret_cast<wa_v4f *>(dst);
+    const int64_t n4 = n_floats >> 2;
+    const int64_t gsz = (int64_t)E * blockDim.x;
+    int64_t i = (int64_t)ebx * blockDim.x + threadIdx.x;
+    for (; i + 3 * gsz < n4; i += 4 * gsz) {
+        wa_v4f a = wa_sweep_ld(s4 + i), b = wa_sweep_ld(s4 + i + gsz), c = wa_sweep_ld(s4 + i + 2 * gsz), d = wa_sweep_ld(s4 + i + 3 * gsz);
+        a *= rho; b *= rho; c *= rho; d *= rho;
+        wa_sweep_st(d4 + i, a); wa_sweep_st(d4 + i + gsz, b); wa_sweep_st(d4 + i + 2 * gsz, c); wa_sweep_st(d4 + i + 3 * gsz, d);
+    }
+    for (; i < n4; i += gsz) {
+        wa_v4f a = wa_sweep_ld(s4 + i);
+        a *= rho;
+        wa_sweep_st(d4 + i, a);
+    }
+    // tail (n_floats is even; at most 2 floats)
+    const int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + threadIdx.x;
+    if (t < n_floats) dst[t] = src[t] * rho;
+}
+
 // ------------------------------------------------------------------ fused post-walk launch (DEV mode)
 // One launch = ranking and deposit marking (blocks [0, 512)) + the evaporation sweep (blocks [512, 512+E)):
 // the sweep only touches the pheromone buffers, rank/mark only the ants' results and the rank
@@ -1036,31 +1063,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
     // their latency-bound work hides under the sweep blocks that follow
     if ((int32_t)blockIdx.x >= 512) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
-        const int32_t ebx = (int32_t)blockIdx.x - 512;
-        const float rho = R.rho;
-        const int64_t n_floats = 6 * D.d.n;
-        const float *src = src_base + (int64_t)slot * D.pher_stride;
-        float *dst = dst_base + (int64_t)slot * D.pher_stride;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        const int64_t n4 = n_floats >> 2;
-        const int64_t gsz = (int64_t)E * blockDim.x;
-        int64_t i = (int64_t)ebx * blockDim.x + tid;
-        for (; i + 3 * gsz < n4; i += 4 * gsz) {
-            float4 a = s4[i], b = s4[i + gsz], c = s4[i + 2 * gsz], d = s4[i + 3 * gsz];
-            a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
-            b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
-            c.x *= rho; c.y *= rho; c.z *= rho; c.w *= rho;
-            d.x *= rho; d.y *= rho; d.z *= rho; d.w *= rho;
-            d4[i] = a; d4[i + gsz] = b; d4[i + 2 * gsz] = c; d4[i + 3 * gsz] = d;
-        }
-        for (; i < n4; i += gsz) {
-            float4 a = s4[i];
-            a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
-            d4[i] = a;
-        }
-        int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + tid;
-        if (t < n_floats) dst[t] = src[t] * rho;
+        wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
+                      (int32_t)blockIdx.x - 512, E);
         return;
     }
     // ---- rank + mark
@@ -1177,29 +1181,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
 __global__ __launch_bounds__(256) void k_evaporate(const float *src_base, float *dst_base,
                                                    int64_t stride, int64_t n_floats, float rho)
 {
-    const float *src = src_base + (int64_t)blockIdx.y * stride;
-    float *dst = dst_base + (int64_t)blockIdx.y * stride;
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *d4 = reinterpret_cast<float4 *>(dst);
-    const int64_t n4 = n_floats >> 2;
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * gsz < n4; i += 4 * gsz) {
-        float4 a = s4[i], b = s4[i + gsz], c = s4[i + 2 * gsz], d = s4[i + 3 * gsz];
-        a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
-        b.x *= rho; b.y *= rho; b.z *= rho; b.w *= rho;
-        c.x *= rho; c.y *= rho; c.z *= rho; c.w *= rho;
-        d.x *= rho; d.y *= rho; d.z *= rho; d.w *= rho;
-        d4[i] = a; d4[i + gsz] = b; d4[i + 2 * gsz] = c; d4[i + 3 * gsz] = d;
-    }
-    for (; i < n4; i += gsz) {
-        float4 a = s4[i];
-        a.x *= rho; a.y *= rho; a.z *= rho; a.w *= rho;
-        d4[i] = a;
-    }
-    // tail (n_floats = 6N is even; at most 2 floats)
-    int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_floats) dst[t] = src[t] * rho;
+    wa_sweep_body(src_base + (int64_t)blockIdx.y * stride, dst_base + (int64_t)blockIdx.y * stride, n_floats, rho,
+                  (int32_t)blockIdx.x, (int32_t)gridDim.x);
 }
 
 // ------------------------------------------------------------------ ranked deposit
