@@ -1,5 +1,7 @@
 """Edge cases of the ACS path on the GPU against the C oracle (DEV mode, bit-exact): degenerate
 inputs, parameter ranges the fast paths do not cover, and the slower generic kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,6 +126,32 @@ def test_exact_path_capacity_and_reuse_of_a_solver(ctx):
     a.reset(1.0)
     a.solve(4, 0, 3, 10.0, fixed_colony=4, mode=O.DEV, seed=1, stream=0)
     assert s.result()[1].tolist() == [4, 3, 2, 1, 0] and np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+
+
+def test_hipgraph_replay_equals_plain_launches(ctx):
+    """WA_GRAPH=G captures G generations of the fused loop once and replays them (kernels read the generation
+    number from a device counter).  Odd chunk sizes exercise the buffer-parity and counter realignment paths."""
+    og = box_grid(12, 12, 12, occ_prob=0.12, seed=3)
+    og.free[0] = og.free[-1] = 1
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, 1.0, 0)
+    p = api.default_params(max_iteration=61, predict=60.0, fixed_colony=20, rng_mode=api.RNG_DEV, seed=5)
+    a = api.AcsSolver(ctx, dg, 1, 20)
+    a.reset_pheromone(1.0)                       # reset() semantics on both sides (out-of-bounds edges hold p0 too)
+    a.solve(p, 0, og.n - 1)
+    os.environ["WA_GRAPH"] = "4"
+    try:
+        b = api.AcsSolver(ctx, dg, 1, 20)
+    finally:
+        del os.environ["WA_GRAPH"]
+    for rounds in range(2):                      # the second begin() must rebuild the graph
+        b.reset_pheromone(1.0)
+        b.begin(p, 0, og.n - 1)
+        for chunk in (3, 9, 1, 8, 5, 4, 31):
+            b.run(chunk)
+        b.sync()
+        assert np.array_equal(bits(a.pheromone()), bits(b.pheromone())) and np.array_equal(a.result()[1], b.result()[1])
+        ta, tb = a.trace(), b.trace()
+        assert np.array_equal(bits(ta["bestL"]), bits(tb["bestL"])) and np.array_equal(ta["steps"], tb["steps"])
 
 
 def test_stepwise_run_equals_single_solve(ctx):

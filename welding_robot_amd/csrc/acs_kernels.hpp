@@ -44,6 +44,8 @@ struct WaAcsDev {
     int32_t max_colony;
     int32_t trace_cap;
     int32_t nb;                    // edges per voxel: 6 (face neighbours) or 26 (faces + edges + corners)
+    int32_t *genbase;              // device generation counter: kernels of the fused DEV loop run generation *genbase + gen_off,
+                                   // which lets a captured hipGraph of G generations be replayed (the graph's last kernel adds G)
 };
 
 // path word = voxel id | (edge index taken to arrive << SHIFT)
@@ -134,6 +136,8 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     wa_next_params(c, R, 0);
     D.ctl[slot] = c;
 }
+
+__global__ void k_set_genbase(WaAcsDev D, int32_t v) { *D.genbase = v; }
 
 // ------------------------------------------------------------------ the walk
 // One wavefront = one ant.  Lanes 0..5 own the six neighbours (edge order of :355-365); the
@@ -611,14 +615,17 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
 // apply_here: the row also APPLIES the pending ranked deposits (mask != 0) of its six edges -- same adds, same
 // ascending rank order as wa_apply_body -- writes them back, clears the masks, and evaluates on the new values.
 __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t row0, int32_t rows, bool apply_here,
-                                              const float *s_dep)
+                                              const float *s_dep, int32_t w_first, int32_t w_first_next)
 {
+    // w_first / w_first_next = bestpath[row0], bestpath[row0 + 1], loaded by the caller before the best length was
+    // known (speculatively, inside the allocation) so that the row's record loads start one round trip earlier
     const WaSlotCtl *ctl = &D.ctl[slot];
     if (ctl->bestL == INFINITY) return;
     const int32_t blen = ctl->best_len;
     const uint32_t ver = ctl->best_ver;
     const float lambda = ctl->dep_lambda, Q = ctl->dep_Q, bestL = ctl->dep_bestL;
     const int32_t k2 = threadIdx.x & 15;
+    const int32_t kk = k2 < 6 ? k2 : 5;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
@@ -626,44 +633,55 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
+    const int32_t dk = wa_delta(kk, D.d.nx, D.d.nxy);
+    const int32_t last_id = (int32_t)D.d.n - 1;
     for (int32_t i = row0; i < blen; i += rows) {
-        const int32_t v = bpath[i] & (int32_t)WA_ID_MASK;
-        float p = -0.f, h = 0.f;
+        const int32_t wv = i == row0 ? w_first : bpath[i];
+        const int32_t wn = i + 1 < blen ? (i == row0 ? w_first_next : bpath[i + 1]) : 0;
+        const int32_t v = wv & (int32_t)WA_ID_MASK;
+        // all record loads of the row are independent of each other
+        const int64_t e = (int64_t)v * 6 + kk;
+        float p = pher[e];
+        const float h = heur[e];
+        unsigned long long m = apply_here ? mask[e] : 0ULL;
+        const uint32_t bt = btabu[i];
+        int32_t nbid = v + dk;
+        nbid = nbid < 0 ? 0 : nbid > last_id ? last_id : nbid;       // (only consulted when the edge was walked: in bounds then)
+        const uint32_t mk = apply_here ? mark[nbid] : 0u;
         bool adm = false;
         if (k2 < 6) {
-            const int64_t e = (int64_t)v * 6 + k2;
-            p = pher[e];
-            h = heur[e];
-            if (apply_here) {
-                unsigned long long m = mask[e];
-                if (m) {  // somebody walked (v, k2): the neighbour is in bounds
-                    const bool onbest = mark[v + wa_delta(k2, D.d.nx, D.d.nxy)] == ver;  // v itself is on the best path (:209)
-                    const float bonus = (float)onbest * lambda * Q / bestL;
-                    while (m) {
-                        int b = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        p += s_dep[b] + bonus;  // :210-211
-                    }
-                    pher[e] = p;
-                    mask[e] = 0;
+            if (m) {  // somebody walked (v, k2): apply the ranked deposits in ascending rank order (:210-211)
+                const bool onbest = mk == ver;  // v itself is on the best path (:209)
+                const float bonus = (float)onbest * lambda * Q / bestL;
+                while (m) {
+                    int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    p += s_dep[b] + bonus;
                 }
+                pher[e] = p;
+                mask[e] = 0;
             }
             // in bounds and free (:148), and not on the prefix best[0..i] (:145-146)
-            adm = (__float_as_uint(p) >> 31) == 0 && !((btabu[i] >> k2) & 1u);
+            adm = (__float_as_uint(p) >> 31) == 0 && !((bt >> k2) & 1u);
+        } else {
+            p = -0.f;
         }
-        const float info = (R.alpha == 1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
+        const float info = (R.alpha == 1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * (k2 < 6 ? h : 0.f);  // :154
         const float a = adm ? info : 0.f;
         float t, c;
         wa_ordered_sums(a, t, c);
         if (k2 < 6) T[(int64_t)i * 8 + k2] = adm ? c : -INFINITY;
         if (k2 == 5) T[(int64_t)i * 8 + 6] = t;
-        if (k2 == 0) T[(int64_t)i * 8 + 7] = __int_as_float(i + 1 < blen ? (int32_t)((uint32_t)bpath[i + 1] >> WA_K_SHIFT) : -1);
+        if (k2 == 0) T[(int64_t)i * 8 + 7] = __int_as_float(i + 1 < blen ? (int32_t)((uint32_t)wn >> WA_K_SHIFT) : -1);
     }
 }
 
 __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 {
-    wa_table_rows(D, R, blockIdx.y, (blockIdx.x * blockDim.x + threadIdx.x) >> 4, (gridDim.x * blockDim.x) >> 4, false, nullptr);
+    const int32_t row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int32_t *bpath = D.bestpath + (int64_t)blockIdx.y * D.path_cap;
+    const int32_t w0 = row0 < D.path_cap ? bpath[row0] : 0, w1 = row0 + 1 < D.path_cap ? bpath[row0 + 1] : 0;
+    wa_table_rows(D, R, blockIdx.y, row0, (gridDim.x * blockDim.x) >> 4, false, nullptr, w0, w1);
 }
 
 // Deposit apply + replay table in ONE launch (DEV fast path, <= 64 depositing ranks): blocks [0, TB) are
@@ -671,15 +689,23 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 // the table depends on -- and blocks [TB, TB + 8*64) are the ordinary apply pass, which skips exactly
 // those edges.  The two roles touch disjoint edges, so no ordering between them is needed.
 #define WA_TABLE_BLOCKS 32
-__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
+__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_t advance)
 {
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y;
+    // last launch of a captured graph of `advance` generations: move the device generation counter on (no block of
+    // this launch reads it; the next launch is ordered after this one)
+    if (advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *D.genbase += advance;
     if ((int32_t)blockIdx.x < WA_TABLE_BLOCKS) {
+        // independent loads first: deposit coefficients, control block, this row's path words
+        const int32_t tid = threadIdx.x, row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+        const float dep_mine = (tid < 64 && tid < D.max_colony) ? D.depA[(int64_t)slot * D.max_colony + tid] : 0.f;
+        const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+        const int32_t w0 = row0 < D.path_cap ? bpath[row0] : 0, w1 = row0 + 1 < D.path_cap ? bpath[row0 + 1] : 0;
         const int32_t n_dep = D.ctl[slot].n_dep;
-        if (threadIdx.x < 64) s_dep[threadIdx.x] = (int32_t)threadIdx.x < n_dep ? D.depA[(int64_t)slot * D.max_colony + threadIdx.x] : 0.f;
+        if (tid < 64) s_dep[tid] = tid < n_dep ? dep_mine : 0.f;
         __syncthreads();
-        wa_table_rows(D, R, slot, (blockIdx.x * blockDim.x + threadIdx.x) >> 4, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep);
+        wa_table_rows(D, R, slot, row0, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep, w0, w1);
         return;
     }
     const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..511: (bx = ab & 7, rank bit = ab >> 3)
@@ -688,11 +714,12 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
 template <bool ALPHA1>
-__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen_off)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
+    const int32_t gen = *D.genbase + gen_off;
     const int32_t colony = c->colony[gen & 1];
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
@@ -1057,7 +1084,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen)
+                                                        float *dst_base, int32_t E, int32_t gen_off)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -1069,6 +1096,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     }
     // ---- rank + mark
     const int32_t mb = (int32_t)blockIdx.x;  // 0..511: (bx = mb & 7, rank bit = mb >> 3)
+    const int32_t gen = *D.genbase + gen_off;
     WaSlotCtl *ctl = &D.ctl[slot];
     const int32_t colony = ctl->colony[gen & 1];
     const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
@@ -1214,31 +1242,42 @@ template <int NB>
 __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
                                               bool skip_best_src, float *s_dep)
 {
+    // The kernel is a chain of dependent global loads (control block -> rank -> ant -> path word -> edge record),
+    // so loads are issued as early as their addresses are known, speculatively where a bound is not yet known
+    // (always inside the allocation): three dependent levels instead of eight.
     const int32_t o = base + bit + 1;
+    const int32_t tid = threadIdx.x, C = D.max_colony;
     const WaSlotCtl *c = &D.ctl[slot];
+    // level 1: addresses that depend only on the launch geometry
+    const float dep_mine = (tid < 64 && base + tid < C) ? D.depA[(int64_t)slot * C + base + tid] : 0.f;
+    const int32_t a = o - 1 < C ? D.perm[(int64_t)slot * C + o - 1] : 0;
     const int32_t n_dep = c->n_dep;
+    const uint32_t ver = c->best_ver;
+    const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
     if (o > n_dep) return;
-    if (threadIdx.x < 64) s_dep[threadIdx.x] = base + (int32_t)threadIdx.x < n_dep ? D.depA[(int64_t)slot * D.max_colony + base + threadIdx.x] : 0.f;
+    if (tid < 64) s_dep[tid] = base + tid < n_dep ? dep_mine : 0.f;
+    // level 2: the ranked ant's length and this thread's first path words
+    const int32_t *path = D.paths + ((int64_t)slot * C + a) * D.path_cap;
+    const int32_t i0 = 1 + bx * (int32_t)blockDim.x + tid;
+    const int32_t len = D.antLen[(int64_t)slot * C + a];
+    int32_t w = i0 < D.path_cap ? path[i0] : 0, pv = i0 < D.path_cap ? path[i0 - 1] : 0;
     __syncthreads();
-    const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
-    const int32_t len = D.antLen[(int64_t)slot * D.max_colony + a];
-    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
-    const uint32_t ver = c->best_ver;
-    const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
-    for (int32_t i = 1 + bx * blockDim.x + threadIdx.x; i < len; i += nbx * blockDim.x) {
-        int32_t w = path[i];
-        int32_t v = path[i - 1] & WaNbT<NB>::IDM;
-        const bool v_best = mark[v] == ver;
-        if (skip_best_src && v_best) continue;
-        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
+    for (int32_t i = i0; i < len; i += nbx * (int32_t)blockDim.x) {
+        if (i != i0) { w = path[i]; pv = path[i - 1]; }
+        const int32_t v = pv & WaNbT<NB>::IDM;
+        const int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
+        // level 3: four independent loads
+        const uint32_t mv = mark[v], mw = mark[w & WaNbT<NB>::IDM];
         unsigned long long m = mask[e];
-        if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
-        bool onbest = v_best && mark[w & WaNbT<NB>::IDM] == ver;      // :209
-        const float bonus = (float)onbest * lambda * Q / bestL;       // second term of :211, the same for every rank
         float p = pher[e];
+        const bool v_best = mv == ver;
+        if (skip_best_src && v_best) continue;
+        if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
+        const bool onbest = v_best && mw == ver;                      // :209
+        const float bonus = (float)onbest * lambda * Q / bestL;       // second term of :211, the same for every rank
         while (m) {
             int b = __ffsll((long long)m) - 1;
             m &= m - 1;

@@ -60,6 +60,10 @@ struct wa_acs {
     WaRun R;
     bool begun, overlap_walk, overlap_rank, fuse, inplace, fuse_table;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
+    // hipGraph of `graph_len` generations of the fused DEV loop (0 = off), valid for the run begun last
+    int32_t graph_len, graph_buf0, genbase_host;
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
     // profiling
@@ -415,6 +419,10 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     s->fuse = env_int("WA_FUSE", 1) != 0;
     s->fuse_table = env_int("WA_FUSE_TABLE", 1) != 0;
     s->inplace = env_int("WA_EVAP_INPLACE", 0) != 0 && !s->overlap_walk;
+    s->graph_len = env_int("WA_GRAPH", 0) & ~1;   // even: the pheromone double buffer is back where it started
+    s->graph = nullptr;
+    s->graph_exec = nullptr;
+    s->genbase_host = 0;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
@@ -436,6 +444,7 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     e = e ? e : dalloc(&D.ctl, S);
     e = e ? e : dalloc(&D.rng, 1);
     e = e ? e : dalloc(&D.dbg, 16);
+    e = e ? e : dalloc(&D.genbase, 1);
     e = e ? e : dalloc(&s->d_starts, S);
     e = e ? e : dalloc(&s->d_ends, S);
     e = e ? e : dalloc(&s->d_streams, S);
@@ -453,6 +462,7 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     HIPC(ctx, hipMemsetAsync(D.vbits, 0, sizeof(uint32_t) * S * C * D.vbits_words, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.ctl, 0, sizeof(WaSlotCtl) * S, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.dbg, 0, sizeof(unsigned long long) * 16, ctx->stream));
+    HIPC(ctx, hipMemsetAsync(D.genbase, 0, sizeof(int32_t), ctx->stream));
     WaGlibcRand r0;
     wa_glibc_seed(&r0, 1);  // a process that never calls srand() behaves as srand(1)
     HIPC(ctx, hipMemcpyAsync(D.rng, &r0, sizeof r0, hipMemcpyHostToDevice, ctx->stream));
@@ -492,7 +502,9 @@ void wa_acs_destroy(wa_acs *s)
     WaAcsDev &D = s->D;
     hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.besttabu); hipFree(D.rtab);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
-    hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg);
+    hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg); hipFree(D.genbase);
+    if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
+    if (s->graph) hipGraphDestroy(s->graph);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
     free_trace(s);
     delete s;
@@ -584,6 +596,10 @@ int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
     HIPC(ctx, hipMemcpyAsync(s->d_ends, he.data(), sizeof(long long) * n_problems, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(s->d_streams, hst.data(), sizeof(uint32_t) * n_problems, hipMemcpyHostToDevice, ctx->stream));
     k_begin<<<(n_problems + 63) / 64, 64, 0, ctx->stream>>>(s->D, R, n_problems, s->d_starts, s->d_ends, s->d_streams);
+    k_set_genbase<<<1, 1, 0, ctx->stream>>>(s->D, 0);
+    s->genbase_host = 0;
+    if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }   // parameters are baked into the nodes
+    if (s->graph) { hipGraphDestroy(s->graph); s->graph = nullptr; }
     if (s->nb == 26) {
         dim3 hg26((unsigned)((s->D.d.n * 26 + 255) / 256), (unsigned)n_problems);
         k_heuristic26<<<hg26, 256, 0, ctx->stream>>>(s->D, R.beta);
@@ -638,7 +654,7 @@ static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float 
 }
 
 // the fused post-walk launch (sweep + rank + mark), timed per dispatch when sampled
-static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int32_t gen, bool timed)
+static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int32_t gen_off, bool timed)
 {
     dim3 grid((unsigned)(s->evap_blocks + 512), (unsigned)P);
     if (timed) {
@@ -647,14 +663,14 @@ static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int
         if (hipEventCreate(&p.a) == hipSuccess) {
             if (hipEventCreate(&p.b) == hipSuccess) {
                 hipExtLaunchKernelGGL(k_evap_rank_mark, grid, dim3(256), 0, s->ctx->stream, p.a, p.b, 0, s->D, s->R, src, dst,
-                                      s->evap_blocks, gen);
+                                      s->evap_blocks, gen_off);
                 s->ev.push_back(p);
                 return;
             }
             hipEventDestroy(p.a);
         }
     }
-    k_evap_rank_mark<<<grid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, s->evap_blocks, gen);
+    k_evap_rank_mark<<<grid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, s->evap_blocks, gen_off);
 }
 
 // One generation = walk -> rank -> evaporate -> deposit (ACSRank_3D.hpp:252-280), enqueued on one
@@ -676,9 +692,67 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     const int32_t chunks = (dep_bound + 63) / 64;
     const bool fused = s->nb == 6 && s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
                        !s->overlap_walk && !s->overlap_rank;
-    for (int32_t g = 0; g < n_generations; g++) {
+    // One generation of the fused DEV loop: walk -> {sweep + rank + mark} -> {apply + replay table}.  gen_off is
+    // relative to the device generation counter; advance != 0 on the last generation of a captured graph.
+    auto enqueue_fused = [&](int32_t gen_off, int32_t advance, bool sampled) {
+        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (s->inplace ? 0 : 1)];
+        EvPair *e = prof_open(s, WA_K_WALK, sampled);
+        if (s->colony_bound > 0) {
+            dim3 wg((unsigned)s->colony_bound, (unsigned)P);
+            if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+            else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+        }
+        prof_close(s, e);
+        launch_fused(s, src, dst, P, gen_off, sampled);
+        if (!s->inplace) s->cur_buf ^= 1;
+        s->D.pher = dst;
+        e = prof_open(s, WA_K_DEPOSIT, sampled);
+        if (s->D.rtab && s->fuse_table) {
+            k_apply_table<<<dim3(WA_TABLE_BLOCKS + 512, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R, advance);
+        } else {
+            k_deposit_apply<6><<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
+            if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+        }
+        prof_close(s, e);
+    };
+    int32_t g0 = 0;
+    // hipGraph replay (WA_GRAPH=G): G generations captured once per run and launched as one graph; the kernels
+    // take their generation number from the device counter, the graph's last kernel advances it by G
+    const int32_t G = s->graph_len;
+    if (fused && G > 0 && !s->prof && s->D.rtab && s->fuse_table && !s->inplace && n_generations >= G) {
+        if (s->graph_exec && s->cur_buf != s->graph_buf0 && n_generations > G) {  // an odd number of plain generations ran since
+            enqueue_fused(s->gens_enqueued - s->genbase_host, 0, false);
+            s->gens_enqueued++;
+            g0++;
+        }
+        if (!s->graph_exec || s->cur_buf == s->graph_buf0) {
+            if (s->genbase_host != s->gens_enqueued) {
+                k_set_genbase<<<1, 1, 0, ctx->stream>>>(s->D, s->gens_enqueued);
+                s->genbase_host = s->gens_enqueued;
+            }
+            if (!s->graph_exec) {
+                s->graph_buf0 = s->cur_buf;
+                HIPC(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                for (int32_t q = 0; q < G; q++) enqueue_fused(q, q == G - 1 ? G : 0, false);
+                HIPC(ctx, hipStreamEndCapture(ctx->stream, &s->graph));
+                HIPC(ctx, hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+            }
+            while (n_generations - g0 >= G) {
+                HIPC(ctx, hipGraphLaunch(s->graph_exec, ctx->stream));
+                g0 += G;
+                s->gens_enqueued += G;
+                s->genbase_host += G;
+            }
+        }
+    }
+    for (int32_t g = g0; g < n_generations; g++) {
         const bool sampled = s->prof && ((s->gens_enqueued % s->prof_every) == 0);
         const int32_t gen = s->gens_enqueued;  // == the device-side generation counter since wa_acs_begin
+        if (fused) {  // DEV fast path: 3 launches
+            enqueue_fused(gen - s->genbase_host, 0, sampled);
+            s->gens_enqueued++;
+            continue;
+        }
         float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (s->inplace ? 0 : 1)];
         if (s->overlap_walk && s->nb == 6) {  // fork the sweep before the walk
             HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -695,28 +769,13 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         } else if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
                 dim3 wg((unsigned)s->colony_bound, (unsigned)P);
-                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
-                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
+                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
+                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
             }
         } else {
             k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
         }
         prof_close(s, e);
-        if (fused) {  // DEV fast path: walk -> {sweep + rank + mark} -> apply
-            launch_fused(s, src, dst, P, gen, sampled);
-            if (!s->inplace) s->cur_buf ^= 1;
-            s->D.pher = dst;
-            e = prof_open(s, WA_K_DEPOSIT, sampled);
-            if (s->D.rtab && s->fuse_table) {
-                k_apply_table<<<dim3(WA_TABLE_BLOCKS + 512, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
-            } else {
-                k_deposit_apply<6><<<dim3(8, 64, (unsigned)P), 256, 0, ctx->stream>>>(s->D, 0);
-                if (s->D.rtab) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
-            }
-            prof_close(s, e);
-            s->gens_enqueued++;
-            continue;
-        }
         if (s->overlap_walk && s->nb == 6) {  // rank on the main stream, join the early sweep
             e = prof_open(s, WA_K_RANK, sampled);
             k_rank<6><<<P, 256, 0, ctx->stream>>>(s->D, s->R, gen);
