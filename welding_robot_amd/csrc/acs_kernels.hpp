@@ -305,29 +305,33 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     for (;;) {
         WA_STAMP(0);                             // loop back-edge + wait for the prefetched record
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
-        const bool act = lane_ok && j == grp;
+        // lane predicates are kept as 64-bit SCALAR masks (one v_cmp each, combined with s_and): a ballot of a
+        // compound lane condition would round-trip through a VGPR (v_cndmask + v_cmp) every time it is tested
+        const unsigned long long actm = 0x3fULL << (grp * 8);   // roles 0..5 of the active group
         {                                        // prefetch the six neighbours' records; every lane loads
             int32_t cur24 = cur * 24;            // (no exec masking): addresses are clamped into the field,
             asm volatile("" : "+s"(cur24));      // an out-of-bounds neighbour is never walked to
-            int32_t boff = cur24 + pf_const;
-            boff = boff < pf_lo ? pf_lo : (boff > pf_hi ? pf_hi : boff);   // < 2 GiB (checked at create)
+            int32_t boff = cur24 + pf_const;     // < 2 GiB (checked at create)
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(boff) : "v"(boff), "v"(pf_lo), "v"(pf_hi));
             pp = *reinterpret_cast<const float *>(pher_b + (uint32_t)boff);
             ph = *reinterpret_cast<const float *>(heur_b + (uint32_t)boff);
         }
         WA_STAMP(1);                             // prefetch issue
         // ---- tabu probe results of the active lanes; collisions (rare) walk the chain here
-        unsigned long long un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
+        unsigned long long un = actm & __ballot(tv != nb) & __ballot(tv != WA_HASH_EMPTY);
         while (__builtin_expect(un != 0, 0)) {
-            if (act && tv != nb && tv != WA_HASH_EMPTY) {
+            if ((un >> lane) & 1ULL) {
                 hs = (hs + 1) & hmask;
                 tv = tab[hs];
             }
-            un = __ballot(act && tv != nb && tv != WA_HASH_EMPTY);
+            un = actm & __ballot(tv != nb) & __ballot(tv != WA_HASH_EMPTY);
         }
         WA_STAMP(2);                             // probe wait + collision check
-        const bool adm = act && (__float_as_uint(p) >> 31) == 0 && tv != nb;  // :145-148
+        // in bounds and free (sign bit clear), not visited (:145-148)
+        const unsigned long long admm = actm & __ballot((int32_t)__float_as_uint(p) >= 0) & __ballot(tv != nb);
         const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
-        const float a = adm ? info : 0.f;  // x + 0.0f == x: padding keeps both sums exact
+        float a;  // adm ? info : 0 -- x + 0.0f == x: padding keeps both sums exact
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(a) : "v"(info), "s"(admm));
         float t, c;  // total -> role 5 of the active group; prob_sum after candidate i -> role i
         wa_ordered_sums(a, t, c);
         const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), grp * 8 + 5));
@@ -339,11 +343,11 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), len & 63));
         } else {
             // no candidate (:162-166) returns before rand() is called: only draw when one exists
-            if (__ballot(adm) == 0) { dead = true; break; }
+            if (admm == 0) { dead = true; break; }
             rnd = (float)wa_glibc_next(rng_r, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
         }
         rnd *= total;                                  // :170
-        const unsigned long long m2 = __ballot(adm && c >= rnd);  // :178
+        const unsigned long long m2 = admm & __ballot(c >= rnd);  // :178
         if (__builtin_expect(m2 == 0, 0)) { dead = true; break; }  // no candidate (:162-166) or fall-through (:191-192)
         const int pick_lane = 63 - __clzll((long long)m2);        // first hit when scanning i = 5..0
         const int pick = pick_lane - grp * 8;
