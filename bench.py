@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-gens", type=int, default=20, help="generations of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10)
+    ap.add_argument("--workload-index", type=int, default=None,
+                    help="run rank R's C4 workload (grid seed 2024+R, colony seed 12345+R) on this GPU; default = own rank")
     return ap.parse_args()
 
 
@@ -113,7 +115,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     ctx = api.Context(local_rank)  # raises if libweldacs.so or the device is missing: no fallback
     n, K, W = args.grid, args.steps, args.warmup
-    wl = wd.per_rank_workload(rank)
+    wl = wd.per_rank_workload(rank if args.workload_index is None else args.workload_index)
     free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=wl["grid_seed"], occ_prob=0.10)
     grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
     ids = grid.resolve(np.array([[0, 0, 0], [n - 1, n - 1, n - 1]], np.float32))

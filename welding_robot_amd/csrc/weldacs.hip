@@ -215,12 +215,16 @@ static int grid_count_free(wa_grid *g)
 {
     wa_ctx *ctx = g->ctx;
     unsigned long long *d_cnt = nullptr, h = 0;
-    HIPC(ctx, hipMalloc((void **)&d_cnt, 8));
-    HIPC(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-    k_count_free<<<1024, 256, 0, ctx->stream>>>(g->occ, g->d.n, d_cnt);
-    HIPC(ctx, hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMalloc((void **)&d_cnt, 8);
+    e = e ? e : hipMemsetAsync(d_cnt, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        k_count_free<<<1024, 256, 0, ctx->stream>>>(g->occ, g->d.n, d_cnt);
+        e = hipGetLastError();
+    }
+    e = e ? e : hipMemcpyAsync(&h, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+    e = e ? e : hipStreamSynchronize(ctx->stream);
     hipFree(d_cnt);
+    if (e != hipSuccess) return fail(ctx, WA_ERR_DEVICE, "free-voxel count: %s", hipGetErrorString(e));
     g->n_free = (int64_t)h;
     return WA_OK;
 }
@@ -321,18 +325,23 @@ int wa_grid_resolve_points(const wa_grid *g, const float *pts_xyz, int32_t n_pts
     wa_ctx *ctx = g->ctx;
     float *d_pts = nullptr;
     long long *d_ids = nullptr;
-    if (dalloc(&d_pts, (size_t)n_pts * 3) || dalloc(&d_ids, (size_t)n_pts)) return fail(ctx, WA_ERR_ALLOC, "resolve buffers");
-    HIPC(ctx, hipMemcpyAsync(d_pts, pts_xyz, sizeof(float) * 3 * n_pts, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(ctx, hipMemsetAsync(d_ids, 0xff, sizeof(long long) * n_pts, ctx->stream));  // -1
-    unsigned blocks = (unsigned)((g->d.n + 255) / 256);
-    k_resolve_points<<<blocks, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
-    HIPC(ctx, hipGetLastError());
     std::vector<long long> h(n_pts);
-    HIPC(ctx, hipMemcpyAsync(h.data(), d_ids, sizeof(long long) * n_pts, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    for (int32_t i = 0; i < n_pts; i++) ids_out[i] = h[i];
+    hipError_t e = dalloc(&d_pts, (size_t)n_pts * 3);
+    e = e ? e : dalloc(&d_ids, (size_t)n_pts);
+    if (e != hipSuccess) { hipFree(d_pts); hipFree(d_ids); return fail(ctx, WA_ERR_ALLOC, "resolve buffers"); }
+    e = hipMemcpyAsync(d_pts, pts_xyz, sizeof(float) * 3 * n_pts, hipMemcpyHostToDevice, ctx->stream);
+    e = e ? e : hipMemsetAsync(d_ids, 0xff, sizeof(long long) * n_pts, ctx->stream);  // -1
+    if (e == hipSuccess) {
+        unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+        k_resolve_points<<<blocks, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
+        e = hipGetLastError();
+    }
+    e = e ? e : hipMemcpyAsync(h.data(), d_ids, sizeof(long long) * n_pts, hipMemcpyDeviceToHost, ctx->stream);
+    e = e ? e : hipStreamSynchronize(ctx->stream);
     hipFree(d_pts);
     hipFree(d_ids);
+    if (e != hipSuccess) return fail(ctx, WA_ERR_DEVICE, "wa_grid_resolve_points: %s", hipGetErrorString(e));
+    for (int32_t i = 0; i < n_pts; i++) ids_out[i] = h[i];
     return WA_OK;
 }
 

@@ -25,13 +25,6 @@
 
 #include "weldacs_dropin.h"
 
-#define SP_IS_EQUAL(x, y) (((x) - (y)) * ((x) - (y)) < 1.e-10)
-#define SP_SAFE_DELETE_AR(p) \
-    if (p) {                 \
-        delete[] p;          \
-        (p) = NULL;          \
-    }
-
 template <typename T, int DIM, int DEGREE, int CONST_LEVEL_INI, int CONST_LEVEL_FIN>
 class BS_Basic {
     static_assert(std::is_same<T, float>::value, "libweldacs evaluates BS_Basic in fp32 only");
