@@ -84,6 +84,40 @@ def test_voxelize_random_mesh_vs_oracle(ctx):
     assert np.array_equal(dg.occupancy(), og.free)
 
 
+def test_voxelize_clipped_equals_dense_form(ctx):
+    """k_voxelize_clip (one workgroup per triangle, voxels of its index box only) against the O(T*N^3) kernel
+    and the oracle, incl. degenerate triangles, a triangle larger than the grid, NaN vertices and walls."""
+    rs = np.random.RandomState(11)
+    v = rs.uniform(-1, 1, (60, 3, 3)).astype(np.float32)
+    v[:20] = v[:20, :1] + rs.uniform(-0.08, 0.08, (20, 3, 3)).astype(np.float32)      # small triangles
+    v[20] = v[20, 0]                                                                   # a point
+    v[21, 2] = v[21, 1]                                                                # a segment
+    v[22] *= 40                                                                        # far larger than everything else
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = n / np.linalg.norm(n, axis=1, keepdims=True)                               # NaN normals for the degenerate ones
+    tris = np.zeros((60, 12), np.float32)
+    tris[:, :3] = n
+    tris[:, 3:] = v.reshape(60, 9)
+    tris = np.delete(tris, 22, axis=0) if False else tris
+    for p, wall in ((0.9, 2), (0.31, 5)):
+        og = O.grid_from_mesh(tris, p, wall)
+        a = api.Grid.from_mesh(ctx, tris, p, wall)
+        os.environ["WA_VOXELIZE_DENSE"] = "1"
+        try:
+            b = api.Grid.from_mesh(ctx, tris, p, wall)
+        finally:
+            del os.environ["WA_VOXELIZE_DENSE"]
+        assert (a.nx, a.ny, a.nz) == (og.nx, og.ny, og.nz)
+        assert np.array_equal(a.occupancy(), og.free) and np.array_equal(b.occupancy(), og.free)
+        assert a.n_free == b.n_free == int(og.free.sum()) and 0 < a.n_free < a.n
+    nan_tri = tris[:3].copy()
+    nan_tri[1, 4] = np.nan
+    og = O.grid_from_mesh(tris[:3], 0.2, 2)                       # (bbox from the finite mesh)
+    a = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    assert a.n == og.n
+
+
 def test_resolve_points_last_match_wins(ctx):
     og = ogrid("cubic.stl", "0.0219", 8)
     dg = dgrid_from(ctx, og)

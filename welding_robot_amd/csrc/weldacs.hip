@@ -95,6 +95,12 @@ static hipError_t dalloc(T **p, size_t count)
     return hipMalloc((void **)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
 }
 
+static int env_int(const char *name, int def)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
+
 extern "C" {
 
 const char *wa_version(void) { return "weldacs 0.1 (gfx950)"; }
@@ -259,9 +265,17 @@ int wa_grid_from_mesh(wa_ctx *ctx, const float *tris, int64_t n_tris, float prec
     if (dalloc(&d_tris, (size_t)n_tris * 12)) { wa_grid_destroy(g); return fail(ctx, WA_ERR_ALLOC, "triangle buffer"); }
     hipError_t ve = hipMemcpyAsync(d_tris, tris, sizeof(float) * 12 * n_tris, hipMemcpyHostToDevice, ctx->stream);
     if (ve == hipSuccess) {
-        unsigned blocks = (unsigned)((g->d.n + 255) / 256);
-        k_voxelize<<<blocks, 256, 0, ctx->stream>>>(d_tris, n_tris, precision, g->d, g->cx, g->cy, g->cz, g->occ);
-        ve = hipGetLastError();
+        if (env_int("WA_VOXELIZE_DENSE", 0)) {   // the O(T*N^3) form, kept for comparison
+            unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+            k_voxelize<<<blocks, 256, 0, ctx->stream>>>(d_tris, n_tris, precision, g->d, g->cx, g->cy, g->cz, g->occ);
+        } else {
+            ve = hipMemsetAsync(g->occ, 1, (size_t)g->d.n, ctx->stream);
+            for (int64_t t0 = 0; ve == hipSuccess && t0 < n_tris; t0 += 1 << 20) {
+                const int64_t cnt = n_tris - t0 < (1 << 20) ? n_tris - t0 : (1 << 20);
+                k_voxelize_clip<<<dim3((unsigned)cnt, 4), 256, 0, ctx->stream>>>(d_tris + t0 * 12, cnt, precision, g->d, g->cx, g->cy, g->cz, g->occ);
+            }
+        }
+        ve = ve ? ve : hipGetLastError();
     }
     if (ve == hipSuccess) ve = hipStreamSynchronize(ctx->stream);
     hipFree(d_tris);
@@ -360,11 +374,6 @@ void wa_acs_default_params(wa_acs_params *p)
     p->seed = 1;
 }
 
-static int env_int(const char *name, int def)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : def;
-}
 
 static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                       int64_t path_capacity, int32_t nb, wa_acs **out)
