@@ -130,6 +130,11 @@ def test_resolve_points_last_match_wins(ctx):
     want = np.array([og.resolve(p) for p in pts])
     got = dg.resolve(pts)
     assert np.array_equal(got, want)
+    os.environ["WA_RESOLVE_DENSE"] = "1"       # the thread-per-voxel form gives the same ids
+    try:
+        assert np.array_equal(dg.resolve(pts), want)
+    finally:
+        del os.environ["WA_RESOLVE_DENSE"]
     assert got[0] == 4130 and got[1] == 17521 and got[3] == -1 and (want == -1).sum() >= 2
     sg = O.synth_grid(128)
     dsg = dgrid_from(ctx, sg)

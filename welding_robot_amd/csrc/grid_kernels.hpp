@@ -111,6 +111,57 @@ __global__ __launch_bounds__(256) void k_resolve_points(WaDims d, const float *_
     }
 }
 
+// Same result with one workgroup per point: the voxels within t of the point on every axis form an index box
+// (read off the axis tables with the same |pt - c| < t comparison); the answer is the largest free id inside it.
+// ids must be pre-filled with -1.
+__global__ __launch_bounds__(256) void k_resolve_points_clip(WaDims d, const float *__restrict__ cx, const float *__restrict__ cy,
+                                                             const float *__restrict__ cz, const uint8_t *__restrict__ free_,
+                                                             float precision, const float *__restrict__ pts, int32_t n_pts,
+                                                             long long *__restrict__ ids)
+{
+    __shared__ int32_t lo[3], hi[3];
+    __shared__ long long best;
+    const int32_t p = blockIdx.x;
+    if (p >= n_pts) return;
+    const float t = (float)(1.2 * (double)precision);  // `float t = 1.2*precision` :544
+    const float qx = pts[3 * p], qy = pts[3 * p + 1], qz = pts[3 * p + 2];
+    if (threadIdx.x < 3) { lo[threadIdx.x] = 0x7fffffff; hi[threadIdx.x] = -1; }
+    if (threadIdx.x == 0) best = -1;
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < d.nx; i += blockDim.x) {
+        float v = qx - cx[i];
+        v = v > 0 ? v : -v;
+        if (v < t) { atomicMin(&lo[0], i); atomicMax(&hi[0], i); }
+    }
+    for (int32_t i = threadIdx.x; i < d.ny; i += blockDim.x) {
+        float v = qy - cy[i];
+        v = v > 0 ? v : -v;
+        if (v < t) { atomicMin(&lo[1], i); atomicMax(&hi[1], i); }
+    }
+    for (int32_t i = threadIdx.x; i < d.nz; i += blockDim.x) {
+        float v = qz - cz[i];
+        v = v > 0 ? v : -v;
+        if (v < t) { atomicMin(&lo[2], i); atomicMax(&hi[2], i); }
+    }
+    __syncthreads();
+    const int32_t x0 = lo[0], y0 = lo[1], z0 = lo[2];
+    const int32_t wx = hi[0] - x0 + 1, wy = hi[1] - y0 + 1, wz = hi[2] - z0 + 1;
+    if (wx <= 0 || wy <= 0 || wz <= 0) return;
+    const int64_t box = (int64_t)wx * wy * wz;
+    long long mine = -1;
+    for (int64_t q = threadIdx.x; q < box; q += blockDim.x) {
+        const int32_t x = x0 + (int32_t)(q % wx), y = y0 + (int32_t)((q / wx) % wy), z = z0 + (int32_t)(q / ((int64_t)wx * wy));
+        const int64_t id = (int64_t)z * d.nxy + (int64_t)y * d.nx + x;
+        if (!free_[id]) continue;
+        float dx = qx - cx[x], dy = qy - cy[y], dz = qz - cz[z];
+        dx = dx > 0 ? dx : -dx; dy = dy > 0 ? dy : -dy; dz = dz > 0 ? dz : -dz;
+        if (dx < t && dy < t && dz < t && id > mine) mine = id;
+    }
+    if (mine >= 0) atomicMax(&best, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) ids[p] = best;
+}
+
 __global__ __launch_bounds__(256) void k_count_free(const uint8_t *__restrict__ free_, int64_t n,
                                                     unsigned long long *__restrict__ out)
 {

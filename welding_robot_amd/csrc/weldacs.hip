@@ -346,8 +346,12 @@ int wa_grid_resolve_points(const wa_grid *g, const float *pts_xyz, int32_t n_pts
     e = hipMemcpyAsync(d_pts, pts_xyz, sizeof(float) * 3 * n_pts, hipMemcpyHostToDevice, ctx->stream);
     e = e ? e : hipMemsetAsync(d_ids, 0xff, sizeof(long long) * n_pts, ctx->stream);  // -1
     if (e == hipSuccess) {
-        unsigned blocks = (unsigned)((g->d.n + 255) / 256);
-        k_resolve_points<<<blocks, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
+        if (env_int("WA_RESOLVE_DENSE", 0)) {   // thread per voxel x every point, kept for comparison
+            unsigned blocks = (unsigned)((g->d.n + 255) / 256);
+            k_resolve_points<<<blocks, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
+        } else {
+            k_resolve_points_clip<<<(unsigned)n_pts, 256, 0, ctx->stream>>>(g->d, g->cx, g->cy, g->cz, g->occ, g->precision, d_pts, n_pts, d_ids);
+        }
         e = hipGetLastError();
     }
     e = e ? e : hipMemcpyAsync(h.data(), d_ids, sizeof(long long) * n_pts, hipMemcpyDeviceToHost, ctx->stream);

@@ -2,7 +2,7 @@
 // of libweldacs.so (include/weldacs.h).  Same type names and public members (Point3, Triangles,
 // Vertex3, GridMap<T>::creatGridMap / readGridMap / ptr_grid_map / size_of_map, the public fields
 // precision, wall, rangeX/Y/Z) so that main.cpp:279 compiles unchanged; the voxelisation itself
-// (reference model_grid_map.hpp:165-268) runs in the k_voxelize HIP kernel.
+// (reference model_grid_map.hpp:165-268) runs in the k_voxelize_clip HIP kernel.
 //
 // Differences a maintainer should know (all opt-outs of reference quirks):
 //  * no #include "matplotlibcpp.h": plot_grid_map/show_plot are no-ops unless the translation unit
