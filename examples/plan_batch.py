@@ -2,7 +2,8 @@
 """BASELINE config C5 in miniature or at full size: P weld points on an n^3 grid, all P(P-1)/2
 pair searches (ACS_Rank::searchBestPathOfPoints' loop, ACSRank_3D.hpp:472-499) batched across the
 slots of each GPU and sharded round-robin across ranks, then the weld-seam order by the ACS-TSP
-kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip).
+kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip), then
+(single-rank runs) the tour's segments stitched and smoothed on the device (main.cpp:283-352).
 
     python examples/plan_batch.py --grid 256 --points 64 --generations 150          # 1 GPU
     torchrun --nproc-per-node 8 examples/plan_batch.py --grid 256 --points 64       # 8 GPUs
@@ -86,6 +87,24 @@ def main():
         out.update(tour_cost=float(tour["L"][0]), tour_iterations=int(tour["iters"][0]),
                    order=[int(e[0]) for e in tour["edges"][0]], t_gtsp_s=time.perf_counter() - t1,
                    pair_generations_per_s=out["pairs"] * args.generations / t_pairs)
+        if world == 1:  # main.cpp:283-352: stitch the tour's segments, then the two smoothing passes, all on the device
+            t2 = time.perf_counter()
+            edges = tour["edges"][0][:-1]
+            segs = [paths[(min(a, b), max(a, b))] for a, b in edges]
+            rev = [1 if a > b else 0 for a, b in edges]          # stored i<j; walk them in tour direction
+            path = api.Trajectory.stitch(grid, segs, rev)
+            ends = path.points()[[0, -1]]
+            s1 = api.Bspline(ctx, 3, 0, 0, 0, len(path))          # BS_Basic<float,3,0,0,0>: time-indexed resampling
+            s1.set_param(ends[0], ends[1], path, 150.0)
+            n1 = max(16, len(path) // 8)
+            _, _, coarse = s1.sample(150.0 / n1, 150.0 / n1, n1, host=False, device=True)
+            s2 = api.Bspline(ctx, 3, 3, 2, 2, len(coarse))        # cubic with zero end velocity / acceleration
+            z = np.zeros((2, 3), np.float32)
+            s2.set_param(np.vstack([ends[:1], z]), np.vstack([ends[1:], z]), coarse, 6000.0)
+            traj, ok = s2.sample(0.0, 1.0, 6001)                  # 1 kHz over 6 s
+            out.update(stitched_nodes=len(path), coarse_points=len(coarse), trajectory_samples=int(ok.sum()),
+                       trajectory_length=float(np.linalg.norm(np.diff(traj, axis=0), axis=1).sum()),
+                       t_trajectory_s=time.perf_counter() - t2)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
