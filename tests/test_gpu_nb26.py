@@ -88,6 +88,30 @@ def test_nb26_batch_and_reset(ctx):
         sb.reset_pheromone(1.0)
 
 
+def test_nb26_replay_on_off_identical(ctx):
+    """Best-path replay (k_replay_table26 + the lane-per-node check) is a pure shortcut: same trace, paths, field."""
+    og = O.synth_grid(40, seed=21, occ_prob=0.08)
+    dg = dgrid_from(ctx, og)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 39, np.float32))
+    p = api.default_params(max_iteration=160, predict=120.0, fixed_colony=64, rng_mode=api.RNG_DEV, seed=4)
+    out = []
+    for replay in ("1", "0"):
+        os.environ["WA_REPLAY"] = replay
+        try:
+            s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=64, neighbourhood=26)
+        finally:
+            del os.environ["WA_REPLAY"]
+        s.solve(p, sid, eid)
+        out.append((s.trace(), s.result(), s.pheromone()))
+        s.close()
+    (ta, ra, pa), (tb, rb, pb) = out
+    assert np.array_equal(bits(ta["bestL"]), bits(tb["bestL"])) and np.array_equal(ta["steps"], tb["steps"])
+    assert np.array_equal(ta["finite"], tb["finite"]) and np.array_equal(bits(ta["iterbestL"]), bits(tb["iterbestL"]))
+    assert bits(ra[0]) == bits(rb[0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+    assert np.array_equal(bits(pa), bits(pb))
+    assert ta["steps"][-1] == (len(ra[1]) - 1) * 64          # converged: every ant walks the best path
+
+
 def test_nb26_shorter_paths_than_6_neighbours(ctx):
     """What the variant is for: diagonal moves shorten the path (Euclidean step lengths)."""
     og = O.synth_grid(48, seed=9, occ_prob=0.05)

@@ -1358,15 +1358,140 @@ __global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta)
     D.heur[(int64_t)slot * D.pher_stride + t] = out;
 }
 
+// ---- best-path replay for the 26-neighbour walk: same idea as wa_walk_replay / k_replay_table.
+// Row of best-path node i = 32 floats: thr[26] (admissible ? prob_sum : -inf), total, edge taken to best[i+1],
+// L accumulated on arrival at node i (the in-order sum of the step lengths, which differ per move type here), pad.
+#define WA_ROW26 32
+__global__ __launch_bounds__(64) void k_replay_table26(WaAcsDev D, WaRun R)
+{
+    const int32_t slot = blockIdx.y, lane = threadIdx.x;
+    const WaSlotCtl *ctl = &D.ctl[slot];
+    if (ctl->bestL == INFINITY) return;
+    const int32_t blen = ctl->best_len;
+    const uint32_t ver = ctl->best_ver;
+    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    float *T = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
+    const int k = lane < 26 ? lane : 25;
+    int dx, dy, dz;
+    wa_off26(k, dx, dy, dz);
+    const int32_t dk = dz * D.d.nxy + dy * D.d.nx + dx;
+    if (blockIdx.x == 0) {  // arrival lengths: one sequential fp32 chain in walk order (:78)
+        // the step lengths are fetched and classified by all lanes (tiles of 1024 through LDS); lane 0 only adds
+        __shared__ float s_d[1024];
+        const float d1 = R.precision, d2 = R.precision * 1.414f, d3 = R.precision * 1.732f;
+        float L = 0.f;
+        if (lane == 0) T[28] = L;
+        for (int32_t base = 1; base < blen; base += 1024) {
+            const int32_t cnt = blen - base < 1024 ? blen - base : 1024;
+            for (int32_t q = lane; q < cnt; q += 64) {
+                int px, py, pz;
+                wa_off26((int)((uint32_t)bpath[base + q] >> WaNbT<26>::SHIFT), px, py, pz);
+                const int type = (px != 0) + (py != 0) + (pz != 0);
+                s_d[q] = type == 1 ? d1 : type == 2 ? d2 : d3;
+            }
+            __syncthreads();
+            if (lane == 0)
+                for (int32_t q = 0; q < cnt; q++) {
+                    L += s_d[q];
+                    T[(int64_t)(base + q) * WA_ROW26 + 28] = L;
+                }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int32_t i = blockIdx.x - 1; i < blen - 1; i += gridDim.x - 1) {   // decisions exist at nodes 0 .. blen-2
+        const int32_t v = bpath[i] & WaNbT<26>::IDM;
+        float p = -0.f, h = 0.f;
+        bool adm = false;
+        if (lane < 26) {
+            p = pher[(int64_t)v * 26 + lane];
+            h = heur[(int64_t)v * 26 + lane];
+            if ((__float_as_uint(p) >> 31) == 0) {            // in bounds and free (:148)
+                const int32_t nb = v + dk;
+                adm = !(mark[nb] == ver && pos[nb] <= i);     // not on the prefix best[0..i] (:145-146)
+            }
+        }
+        const float info = wa_powi(fabsf(p), R.alpha) * h;    // :154
+        const float a = adm ? info : 0.f;
+        float t = 0.f + a, c = 0.f + a;
+#pragma unroll
+        for (int q = 0; q < 25; q++) {
+            t = dpp_wave_from_below(t) + a;
+            c = dpp_wave_from_above(c) + a;
+        }
+        float *row = T + (int64_t)i * WA_ROW26;
+        if (lane < 26) row[lane] = adm ? c : -INFINITY;
+        if (lane == 25) row[26] = t;
+        if (lane == 0) row[27] = __int_as_float((int32_t)((uint32_t)bpath[i + 1] >> WaNbT<26>::SHIFT));
+    }
+}
+
+// one lane per node, 64 nodes per ballot.  Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).
+__device__ __forceinline__ int wa_walk_replay26(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node)
+{
+    const int lane = threadIdx.x;
+    const float4 *__restrict__ T4 = reinterpret_cast<const float4 *>(T);
+    const int32_t last = rlen - 1;
+    for (int32_t i0 = 0;; i0 += 64) {
+        const int32_t nodev = i0 + lane;
+        const bool valid = nodev < last;
+        const int32_t nv = valid ? nodev : last - 1;
+        float4 r[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) r[q] = T4[(int64_t)nv * (WA_ROW26 / 4) + q];
+        float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;   // :169
+        rnd *= r[6].z;                                                              // total (:170)
+        const int nk = __float_as_int(r[6].w);
+        uint32_t h = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            h |= (r[q].x >= rnd ? 1u : 0u) << (4 * q);
+            h |= (r[q].y >= rnd ? 1u : 0u) << (4 * q + 1);
+            if (q < 6) {
+                h |= (r[q].z >= rnd ? 1u : 0u) << (4 * q + 2);
+                h |= (r[q].w >= rnd ? 1u : 0u) << (4 * q + 3);
+            }
+        }
+        const int pick = h ? 31 - __clz((int)h) : -1;     // first hit scanning 25..0 (:172-189)
+        const unsigned long long fm = __ballot(valid && pick != nk);
+        if (__builtin_expect(fm != 0, 0)) {
+            const int g = __ffsll((long long)fm) - 1;
+            node = i0 + g;
+            return __builtin_amdgcn_readlane((int)h, g) ? 3 : 1;
+        }
+        if (i0 + 64 >= last) { node = last; return 2; }
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant, int32_t start,
                                               int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t *rng_r,
-                                              int32_t &rng_f, int32_t &rng_b, int32_t *flags_out)
+                                              int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    int32_t r_node = 0;
+    float r_L = 0.f;
+    if (MODE == 1 && rlen > 1) {   // follow the best path while the ant's own draws take its edges
+        const float *RT = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
+        const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+        const int what = wa_walk_replay26(RT, rlen, antkey, r_node);
+        for (int32_t q = lane; q <= r_node; q += 64) path[q] = bpath[q];   // the walked prefix IS the best path's
+        r_L = RT[(int64_t)r_node * WA_ROW26 + 28];                          // L on arrival at that node
+        if (what != 3) {
+            if (lane == 0) {
+                D.antL[(int64_t)slot * D.max_colony + ant] = what == 2 ? r_L : INFINITY;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = r_node + 1;
+            }
+            return;
+        }
+    }
     WaTabu T;
     T.tab = tab;
     T.mask = (1u << hash_log2) - 1u;
@@ -1377,10 +1502,20 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
     for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    if (r_node > 0) {   // deviated at best[r_node]: tabu set := the replayed prefix (distinct keys: concurrent CAS inserts)
+        const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+        if (r_node + 1 <= spill_at) {
+            for (int32_t q = lane; q <= r_node; q += 64) {
+                const int32_t key = bpath[q] & WaNbT<26>::IDM;
+                uint32_t h = ((uint32_t)key * 2654435761u) >> T.shift;
+                while (atomicCAS(&tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & T.mask;
+            }
+        }   // (a longer prefix goes straight to the bitmap: the loop below spills from path[] when len > spill_at)
+    } else if (lane == 0) {
         tabu_insert(T, start);  // addStartNode :81-86
         path[0] = start;
     }
+    __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     // lane constants: neighbour offset, in-bounds test inputs, step length by move type (:369-385)
     const int k = lane < 26 ? lane : 25;
@@ -1391,6 +1526,12 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     int32_t cur = start, len = 1;
     uint32_t step = 0;
     float L = 0.f;
+    if (r_node > 0) {
+        cur = D.bestpath[(int64_t)slot * D.path_cap + r_node] & WaNbT<26>::IDM;
+        len = r_node + 1;
+        step = (uint32_t)r_node;   // steps taken so far = draws consumed
+        L = r_L;
+    }
     float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
     const int64_t last_rec = (D.d.n - 1) * 26;
     for (;;) {
@@ -1486,7 +1627,8 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
     if (ant >= colony || colony > D.max_colony) return;
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0;
-    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags);
+    const int32_t rlen = (D.rtab && c->bestL != INFINITY) ? c->best_len : 0;
+    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen);
 }
 
 __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
@@ -1501,7 +1643,7 @@ __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags);
+        wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;

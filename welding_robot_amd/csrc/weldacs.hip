@@ -455,7 +455,8 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
     e = e ? e : dalloc(&D.bestpos, S * n);
     e = e ? e : dalloc(&D.besttabu, S * path_capacity);
-    if (nb == 6 && env_int("WA_REPLAY", 1) != 0) e = e ? e : dalloc(&D.rtab, S * path_capacity * 8 + 256);  // + slack: the replay reads whole 16-node chunks
+    if (env_int("WA_REPLAY", 1) != 0)   // replay table: 8 floats per best-path node (6 neighbours) / 32 (26 neighbours)
+        e = e ? e : dalloc(&D.rtab, S * path_capacity * (nb == 6 ? 8 : WA_ROW26) + 256);
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
     e = e ? e : dalloc(&D.antLen, S * C);
@@ -831,7 +832,10 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
                 k_deposit_apply<6><<<dg, 256, 0, ctx->stream>>>(s->D, c * 64);
             }
         }
-        if (s->D.rtab && s->R.rng_mode == WA_RNG_DEV) k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+        if (s->D.rtab && s->R.rng_mode == WA_RNG_DEV) {
+            if (s->nb == 26) k_replay_table26<<<dim3(257, (unsigned)P), 64, 0, ctx->stream>>>(s->D, s->R);
+            else k_replay_table<<<dim3(32, (unsigned)P), 256, 0, ctx->stream>>>(s->D, s->R);
+        }
         prof_close(s, e);
         s->gens_enqueued++;
     }
