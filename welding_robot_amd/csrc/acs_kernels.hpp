@@ -1304,8 +1304,8 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
 // in comments restored: edge neighbours precision*1.414f, corner neighbours precision*1.732f).
 // Edge order = the reference's cube loop: z offset outermost, then y, then x, centre skipped.
 // Same selectNext, same ranking, same deposit; pheromone / heuristic / rank-mask fields are [N][26].
-// One wavefront per ant, lane k < 26 owns neighbour k.  This is the plain loop (LDS hash tabu with
-// bitmap spill, ordered sums by broadcast), without the 6-neighbour path's prefetching and replay.
+// One wavefront per ant, lane k < 26 owns neighbour k: LDS hash tabu with bitmap spill, ordered sums as
+// whole-wave DPP chains, cache-warming loads for the next step's records, best-path replay (k_replay_table26).
 // =====================================================================================================
 __device__ __forceinline__ void wa_off26(int k, int &dx, int &dy, int &dz)
 {
