@@ -2,7 +2,7 @@
 """hipGraph replay of the generation loop (WA_GRAPH=G): generations/s with the per-dispatch profiling OFF, at the
 benchmark size and at the reference's small demo sizes, where the loop is launch-bound."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api

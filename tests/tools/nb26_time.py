@@ -2,7 +2,7 @@
 """26-neighbour variant at the benchmark size (128^3 synthetic grid, 256 ants): generations/s and per-kernel time,
 beside the 6-neighbour path on the same grid, and the CPU port for a few generations."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api, synth

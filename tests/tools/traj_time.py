@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the trajectory kernels (stitch, spline setup, batched evaluation) and time the CPU oracle beside them."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api

@@ -2,7 +2,7 @@
 """Time the voxelisation (mesh -> occupancy on the device) at several precisions: the triangle-clipped kernel
 (default) and the O(T*N^3) form (WA_VOXELIZE_DENSE=1); check against the oracle at the small one."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api
