@@ -40,13 +40,15 @@ def test_no_torch_or_cxx_types_in_abi():
 
 
 def test_product_never_links_the_oracle():
-    pkg = os.path.join(ROOT, "welding_robot_amd")
-    for dp, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
-                txt = open(os.path.join(dp, f), errors="ignore").read()
-                bad = re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|libweld_oracle|oracle_lib|_ref/', txt)
-                assert not bad, (os.path.join(dp, f), bad.group(0))
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load anything under oracle/:
+    the package, the public header, the examples and tools/ must not."""
+    for sub in ("welding_robot_amd", "include", "examples", "tools"):
+        for dp, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    bad = re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|libweld_oracle|oracle_lib|_ref/', txt)
+                    assert not bad, (os.path.join(dp, f), bad.group(0))
 
 
 def _has_gpu(lib):
