@@ -5,7 +5,7 @@
 //
 //   g++ -std=c++14 -Iinclude -Iwelding_robot_amd/include examples/dropin_demo.cpp
 //       -Lwelding_robot_amd/lib -lweldacs -Wl,-rpath,$PWD/welding_robot_amd/lib -o dropin_demo
-//   ./dropin_demo cubic.stl 0.0219 8 points.in 0.5 graph.in [ref SEED | dev SEED] [out.txt]
+//   ./dropin_demo cubic.stl 0.0219 8 points.in 0.5 graph.in [ref SEED | dev SEED | dev-dense SEED] [out.txt]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,6 +32,7 @@ int main(int argc, char **argv)
         SearchPath.setGraphFileCompat(true);
         GlobalRoute.setRngMode(WA_RNG_REF);
     }
+    if (!strcmp(mode, "dev-dense")) SearchPath.setLazyEvaporation(false);  // same results through the dense sweep
     SearchPath.setSeed(seed);
     GlobalRoute.setSeed(seed);
 

@@ -27,12 +27,12 @@ from welding_robot_amd import api, synth  # noqa: E402
 from welding_robot_amd import dist as wd  # noqa: E402
 
 
-def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=1, fixed_colony=0):
+def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=1, fixed_colony=0, lazy=False):
     P = len(point_ids)
     pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
     mine = wd.shard_problems(len(pairs), rank, world)
     colony = fixed_colony or max(1, int(0.35 * predict / float(grid.precision)))
-    solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony)
+    solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony, lazy=lazy)
     p = api.default_params(max_iteration=generations, predict=predict, fixed_colony=fixed_colony,
                            rng_mode=api.RNG_DEV, seed=seed)
     cost = np.zeros((P, P), np.float64)
@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--generations", type=int, default=150)
     ap.add_argument("--slots", type=int, default=16)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--lazy", action="store_true",
+                    help="wa_acs_create_lazy: never-deposited voxels are not swept (same results, O(deposited voxels) per generation)")
     args = ap.parse_args()
     rank, local_rank, world = wd.env_rank()
     if world > 1:
@@ -72,14 +74,14 @@ def main():
     pts = synth.synth_weld_points(free, n, args.points, seed=args.seed)
     predict = float(0.35 ** -1 * 24)  # 24 ants per search at precision 1 (ACSRank_3D.hpp:247)
     t0 = time.perf_counter()
-    cost, paths, n_mine = plan(ctx, grid, pts, args.generations, predict, args.seed, args.slots, rank, world)
+    cost, paths, n_mine = plan(ctx, grid, pts, args.generations, predict, args.seed, args.slots, rank, world, lazy=args.lazy)
     if world > 1:
         t = torch.from_numpy(cost).cuda()
         dist.all_reduce(t)  # every pair is owned by exactly one rank
         cost = t.cpu().numpy()
     t_pairs = time.perf_counter() - t0
     finite = np.isfinite(cost).all()
-    out = dict(grid=n, points=args.points, pairs=args.points * (args.points - 1) // 2, world=world,
+    out = dict(grid=n, points=args.points, lazy_evaporation=bool(args.lazy), pairs=args.points * (args.points - 1) // 2, world=world,
                pairs_this_rank=n_mine, t_pairs_s=t_pairs, all_reached=bool(finite))
     if rank == 0 and finite:
         t1 = time.perf_counter()

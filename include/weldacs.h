@@ -116,6 +116,16 @@ int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max
  * wa_acs_result's `choices` are 0..25. */
 int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                      int64_t path_capacity, int32_t neighbourhood, wa_acs **out);
+/* Same results as wa_acs_create, evaporation evaluated LAZILY: a voxel none of whose outgoing edges ever received a
+ * deposit is never swept -- after g evaporations each of its in-bounds edges holds pheromone_0*rho*...*rho in the
+ * reference's own fp32 rounding, which the solver carries as one scalar -- and only the voxels on deposited paths
+ * are multiplied by rho every generation (ACSRank_3D.hpp:268-272 restricted to where it can differ).  Every value
+ * any kernel reads, and wa_acs_read_pheromone's output, is bit-identical to the dense sweep.  A generation then
+ * costs O(deposited voxels) instead of 48 B/voxel and reset_pheromone O(deposited voxels) instead of 24 B/voxel:
+ * meant for many pair searches on large grids (BASELINE config C5).  DEV mode, 6 neighbours, <= 2048 ants and
+ * <= 64 depositing ranks only (WA_ERR_ARG at wa_acs_begin otherwise); wa_acs_evaporate is not available. */
+int wa_acs_create_lazy(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                       int64_t path_capacity, wa_acs **out);
 void wa_acs_destroy(wa_acs *s);
 /* initFromGridMap :343-408: in-bounds edges pheromone_0, out-of-bounds edges 0. slot<0: all */
 int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float pheromone_0);

@@ -102,6 +102,10 @@ def test_dropin_pipeline_dev_mode_is_deterministic_and_sane():
     assert sorted(da["edges"][::2]) == [0, 1, 2, 3, 4]  # a Hamiltonian tour over the 5 weld points
     costs = np.array([da["cost"][(i, j)] for i in range(5) for j in range(5) if i != j])
     assert np.all(np.isfinite(costs)) and np.all(costs > 0)
+    # lazy evaporation (the DEV default) and the dense sweep give the same bytes
+    c = "/tmp/weldacs_dropin_dev_c.txt"
+    assert run_demo("dev-dense", 7, c).returncode == 0
+    assert open(a, "rb").read() == open(c, "rb").read()
     # the correct (non-compat) graph file parses back to the in-memory matrix
     tok = open(a + ".graph").read().split()
     assert tok[:2] == ["5", "10"] and np.float32(tok[2]) == da["cost"][(0, 1)]

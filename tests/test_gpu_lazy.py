@@ -1,0 +1,152 @@
+"""Lazy evaporation (wa_acs_create_lazy): voxels that never received a deposit are not swept; their edges are worth
+one scalar, pheromone_0*rho*...*rho in fp32 rounding.  Everything observable -- traces, paths, the full pheromone
+field read back -- must be bit-identical to the C oracle's dense evaporation (and hence to the dense solver)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_gpu_parity import _dev_vs_oracle, bits, dgrid_from, ogrid
+from welding_robot_amd import api
+from welding_robot_amd._lib import WeldacsError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def test_lazy_cubic_and_adaptive_colony(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    _dev_vs_oracle(ctx, og, sid, eid, 50, 1.03, 16, seed=12345, lazy=True)
+    _dev_vs_oracle(ctx, og, sid, eid, 150, 5.0, 0, seed=7, stream=3, lazy=True)     # adaptive colony (Q1)
+    _dev_vs_oracle(ctx, og, sid, eid, 60, 1.03, 24, seed=9, alpha=2, lazy=True)     # power() path
+
+
+def test_lazy_no_rank_deposits(ctx):
+    """colony 4 => lambda - 1 < 1: nobody ever deposits, every voxel stays clean, the whole field is the scalar."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    _dev_vs_oracle(ctx, og, sid, eid, 40, 1.03, 4, seed=3, lazy=True)
+
+
+def test_lazy_seam_all_ants_die(ctx):
+    og = ogrid("cubic.stl", "0.0225", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    t = _dev_vs_oracle(ctx, og, sid, eid, 10, 1.03, 0, seed=1, lazy=True)
+    assert np.all(np.isinf(t["bestL"]))
+
+
+def test_lazy_piece_c2_and_synth(ctx):
+    og = ogrid("simplified_piece.stl", "0.0148", 4)
+    _dev_vs_oracle(ctx, og, 2177, 48575, 200, 5.4126, 128, seed=12345, lazy=True)
+    og = O.synth_grid(64, seed=77, occ_prob=0.15)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 63, np.float32))
+    _dev_vs_oracle(ctx, og, sid, eid, 40, 300.0, 96, seed=99, lazy=True)
+
+
+def test_lazy_c3_first_generations(ctx):
+    og = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    _dev_vs_oracle(ctx, og, 16513, 2097151, 6, 731.43, 256, seed=12345, lazy=True)
+
+
+def test_lazy_denormal_tail(ctx):
+    """500 evaporations drive the clean value through the denormals to 0 exactly like the sweep."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    _dev_vs_oracle(ctx, og, sid, eid, 500, 1.03, 16, seed=2, lazy=True)
+
+
+def test_lazy_spill_to_bitmap(ctx):
+    og = ogrid("cubic.stl", "0.0219", 8)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    os.environ["WA_HASH_LOG2"] = "6"
+    try:
+        _dev_vs_oracle(ctx, og, sid, eid, 30, 1.03, 16, seed=5, lazy=True)
+    finally:
+        del os.environ["WA_HASH_LOG2"]
+
+
+def test_lazy_batch_reset_and_reuse(ctx):
+    """pair flow: batched slots, reset_pheromone between rounds (rewrites the dirty records only), and a round WITHOUT
+    reset in between (the clean scalar and the dirty set carry over)."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12)]
+    ids = [og.resolve(og.node_pt(*n)) for n in nodes]
+    pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+    p = api.default_params(max_iteration=40, predict=0.5, rng_mode=api.RNG_DEV, seed=2024)
+    sb = api.AcsSolver(ctx, dg, n_slots=len(pairs), max_colony=8, lazy=True)
+    oracles = [O.Acs(og) for _ in pairs]
+    for rnd, do_reset in enumerate([True, True, False, True]):
+        if do_reset:
+            sb.reset_pheromone(1.0)
+        sb.solve(p, [ids[i] for i, _ in pairs], [ids[j] for _, j in pairs], streams=[k + 100 * rnd for k in range(len(pairs))])
+        for k, (i, j) in enumerate(pairs):
+            a = oracles[k]
+            if do_reset:
+                a.reset(1.0)
+            a.solve(ids[i], ids[j], 40, 0.5, mode=O.DEV, seed=2024, stream=k + 100 * rnd)
+            cost, path, _ = sb.result(k)
+            assert bits(cost) == bits(a.best_L)
+            if np.isfinite(cost):
+                assert np.array_equal(path, a.best_path()[0])
+            assert np.array_equal(bits(sb.pheromone(k)), bits(a.pheromone())), (rnd, k)
+
+
+def test_lazy_init_then_reset_switches_mode(ctx):
+    """init (out-of-bounds edges 0) and reset (every edge p0) differ on the boundary: the switch takes the full pass."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    s = api.AcsSolver(ctx, dg, 1, 16, lazy=True)
+    p = api.default_params(max_iteration=20, predict=1.03, fixed_colony=16, rng_mode=api.RNG_DEV, seed=1)
+    a = O.Acs(og)
+    for step in ("init", "reset", "reset", "init"):
+        if step == "reset":
+            s.reset_pheromone(0.5); a.reset(0.5)
+            p.pheromone_0 = 0.5
+        else:
+            s.init_pheromone(1.0); a = O.Acs(og)
+            p.pheromone_0 = 1.0
+        s.solve(p, sid, eid)
+        a.solve(sid, eid, 20, 1.03, fixed_colony=16, mode=O.DEV, seed=1, pheromone_0=p.pheromone_0)
+        assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), step
+
+
+def test_lazy_stepwise_runs(ctx):
+    og = O.synth_grid(24, seed=3, occ_prob=0.12)
+    dg = dgrid_from(ctx, og)
+    sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, 23, np.float32))
+    p = api.default_params(max_iteration=45, predict=80.0, fixed_colony=20, rng_mode=api.RNG_DEV, seed=5)
+    a = api.AcsSolver(ctx, dg, 1, 20)
+    a.solve(p, sid, eid)
+    b = api.AcsSolver(ctx, dg, 1, 20, lazy=True)
+    b.begin(p, sid, eid)
+    for chunk in (1, 7, 2, 20, 15):
+        b.run(chunk)
+    b.sync()
+    assert np.array_equal(bits(a.pheromone()), bits(b.pheromone())) and np.array_equal(a.result()[1], b.result()[1])
+    assert np.array_equal(bits(a.trace()["bestL"]), bits(b.trace()["bestL"]))
+
+
+def test_lazy_refuses_what_it_cannot_run(ctx):
+    og = O.synth_grid(8, seed=1)
+    dg = dgrid_from(ctx, og)
+    s = api.AcsSolver(ctx, dg, 1, 16, lazy=True)
+    with pytest.raises(WeldacsError) as e:
+        s.solve(api.default_params(max_iteration=3, predict=10.0, fixed_colony=16, rng_mode=api.RNG_REF), 0, og.n - 1)
+    assert e.value.code == 1
+    with pytest.raises(WeldacsError) as e:
+        s.evaporate(0, 0.8, 1)
+    assert e.value.code == 8
+    big = api.AcsSolver(ctx, dg, 1, 400, lazy=True)
+    with pytest.raises(WeldacsError) as e:      # lambda = 80 ranks > 64
+        big.solve(api.default_params(max_iteration=3, predict=10.0, fixed_colony=400, rng_mode=api.RNG_DEV), 0, og.n - 1)
+    assert e.value.code == 1

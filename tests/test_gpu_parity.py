@@ -252,14 +252,14 @@ def test_gtsp_ref_mode_equals_reference(ctx, tag, seed):
 
 
 # ------------------------------------------------------------------ ACS, DEV mode == C oracle in DEV mode
-def _dev_vs_oracle(ctx, og, sid, eid, iters, predict, fixed, seed, stream=0, max_colony=None, nb=6, **solver_kw):
+def _dev_vs_oracle(ctx, og, sid, eid, iters, predict, fixed, seed, stream=0, max_colony=None, nb=6, alpha=1, **solver_kw):
     dg = dgrid_from(ctx, og)
     bound = fixed if fixed else int(0.35 * predict / float(og.precision))
     s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max_colony or max(bound, 1), neighbourhood=nb, **solver_kw)
-    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_DEV, seed=seed)
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_DEV, seed=seed, alpha=alpha)
     s.solve(p, sid, eid, streams=[stream])
     a = O.Acs(og, nb=nb)
-    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream)
+    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream, alpha=alpha)
     t = s.trace()
     assert np.array_equal(t["steps"], tr["steps"]), (t["steps"][:5], tr["steps"][:5])
     assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))

@@ -144,10 +144,14 @@ def default_params(**kw):
 
 
 class AcsSolver:
-    def __init__(self, ctx, grid, n_slots=1, max_colony=256, path_capacity=0, neighbourhood=6):
+    def __init__(self, ctx, grid, n_slots=1, max_colony=256, path_capacity=0, neighbourhood=6, lazy=False):
         self.ctx, self.grid, self.n_slots, self.max_colony, self.nb = ctx, grid, n_slots, max_colony, neighbourhood
         h = C.c_void_p()
-        ctx.check(ctx.lib.wa_acs_create_nb(ctx.h, grid.h, n_slots, max_colony, path_capacity, neighbourhood, C.byref(h)))
+        if lazy:
+            assert neighbourhood == 6
+            ctx.check(ctx.lib.wa_acs_create_lazy(ctx.h, grid.h, n_slots, max_colony, path_capacity, C.byref(h)))
+        else:
+            ctx.check(ctx.lib.wa_acs_create_nb(ctx.h, grid.h, n_slots, max_colony, path_capacity, neighbourhood, C.byref(h)))
         self.h = h
         self.iters = 0
         ctx._children.add(self)

@@ -44,6 +44,13 @@ struct WaAcsDev {
     int32_t max_colony;
     int32_t trace_cap;
     int32_t nb;                    // edges per voxel: 6 (face neighbours) or 26 (faces + edges + corners)
+    // lazy evaporation: a voxel whose six outgoing edges never received a deposit ("clean") is not swept; its edges
+    // are worth ctl.clean (or 0 where the stored value is 0).  dirty = one byte per voxel, dirty_list = the swept set,
+    // dcount[slot][2] = {entries swept by the next sweep, append cursor}.  All null in the (default) dense mode.
+    uint8_t *dirty;                // [slot][n4] (n rounded up to 4)
+    int32_t *dirty_list;           // [slot][n]
+    int32_t *dcount;               // [slot][2]
+    int64_t dirty_stride;
     int32_t *genbase;              // device generation counter: kernels of the fused DEV loop run generation *genbase + gen_off,
                                    // which lets a captured hipGraph of G generations be replayed (the graph's last kernel adds G)
 };
@@ -128,6 +135,7 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.start = (int32_t)starts[slot];
     c.end = (int32_t)ends[slot];
     c.stream = streams ? streams[slot] : (uint32_t)slot;
+    c.clean[0] = c.clean[c.gen & 1];   // lazy evaporation: the field's clean value carries over; generation parity restarts
     c.gen = 0;
     c.bestL = INFINITY;  // :232; the best PATH is kept (Q9) but unreachable while bestL is inf
     c.best_len = 0;
@@ -246,9 +254,10 @@ struct WaWalkState {
 // round trip on the critical path (CDNA4 counts stores in vmcnt and the data VGPR cannot be
 // reused before the store retires).  Instead lane (len & 63) captures the word in a VGPR and
 // the wave flushes 64 consecutive path entries with ONE coalesced 256-byte store.
-template <int MODE, bool ALPHA1>
+template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__restrict__ pher,
-                                             const float *__restrict__ heur, int32_t *__restrict__ path,
+                                             const float *__restrict__ heur, const uint8_t *__restrict__ dirty, float clean_info,
+                                             int32_t *__restrict__ path,
                                              int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
                                              int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
                                              int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out,
@@ -285,6 +294,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     int grp = 0;             // group holding the record of `cur`
     float ublock = 0.f;      // DEV: lane i holds the uniform draw of the step with (len & 63) == i
     float pp = -0.f, ph = 0.f;
+    uint32_t pd = 1;         // SPARSE: dirty flag of the voxel whose record pp/ph belong to (clean => edges are worth clean_info)
     // software pipeline: the record of `cur` (pp/ph) and the tabu probe of its neighbours (tv/hs)
     // are issued one step early, right after `cur` became known, and consumed at the loop top
     int32_t nb = cur + dk;
@@ -295,6 +305,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         pp = *reinterpret_cast<const float *>(pher_b + boff);
         ph = *reinterpret_cast<const float *>(heur_b + boff);
     }
+    if (SPARSE) pd = dirty[cur];
     tv = tab[hs];            // every lane probes (unmasked): only the active group's result is used
     if (MODE == 1) ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
     bool dead = false;
@@ -305,6 +316,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     for (;;) {
         WA_STAMP(0);                             // loop back-edge + wait for the prefetched record
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
+        const uint32_t pdirty = pd;
         // lane predicates are kept as 64-bit SCALAR masks (one v_cmp each, combined with s_and): a ballot of a
         // compound lane condition would round-trip through a VGPR (v_cndmask + v_cmp) every time it is tested
         const unsigned long long actm = 0x3fULL << (grp * 8);   // roles 0..5 of the active group
@@ -315,6 +327,11 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             asm("v_med3_i32 %0, %1, %2, %3" : "=v"(boff) : "v"(boff), "v"(pf_lo), "v"(pf_hi));
             pp = *reinterpret_cast<const float *>(pher_b + (uint32_t)boff);
             ph = *reinterpret_cast<const float *>(heur_b + (uint32_t)boff);
+            if (SPARSE) {                        // the neighbour's dirty byte travels with its record
+                int32_t vj = cur + dj;
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(vj) : "v"(vj), "v"(0), "v"(last_id));
+                pd = dirty[vj];
+            }
         }
         WA_STAMP(1);                             // prefetch issue
         // ---- tabu probe results of the active lanes; collisions (rare) walk the chain here
@@ -329,7 +346,9 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         WA_STAMP(2);                             // probe wait + collision check
         // in bounds and free (sign bit clear), not visited (:145-148)
         const unsigned long long admm = actm & __ballot((int32_t)__float_as_uint(p) >= 0) & __ballot(tv != nb);
-        const float info = (ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha)) * h;  // :154
+        float pa = ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha);
+        if (SPARSE) pa = pdirty ? pa : clean_info;                                // never-deposited voxel: every admissible edge holds the clean value
+        const float info = pa * h;                                                // :154
         float a;  // adm ? info : 0 -- x + 0.0f == x: padding keeps both sums exact
         asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(a) : "v"(info), "s"(admm));
         float t, c;  // total -> role 5 of the active group; prob_sum after candidate i -> role i
@@ -397,8 +416,9 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
 }
 
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
-template <int MODE>
+template <int MODE, bool SPARSE>
 __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, const float *pher, const float *heur,
+                                          const uint8_t *dirty, float clean_info,
                                           int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t *rng_r,
                                           int32_t &rng_f, int32_t &rng_b, int32_t spill_at, WaWalkState &st,
                                           int32_t *flags_out)
@@ -429,7 +449,9 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
             h = heur[(int64_t)cur * 6 + k];
             if ((__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);
         }
-        float info = wa_powi(fabsf(p), R.alpha) * h;
+        float pa = wa_powi(fabsf(p), R.alpha);
+        if (SPARSE) pa = dirty[cur] ? pa : clean_info;
+        float info = pa * h;
         uint32_t m = (uint32_t)__ballot(adm) & 0x3fu;
         if (m == 0) { L = INFINITY; break; }
         float v[6];
@@ -533,15 +555,17 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32
     }
 }
 
-template <int MODE, bool ALPHA1>
+template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
-                                            int32_t *flags_out, int32_t rlen, float bestL)
+                                            int32_t *flags_out, int32_t rlen, float bestL, float clean)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    const uint8_t *dirty = SPARSE ? D.dirty + (int64_t)slot * D.dirty_stride : nullptr;
+    const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     WaWalkState st;
@@ -591,7 +615,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     __builtin_amdgcn_wave_barrier();
     const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
     if (st.len < fast_limit)
-        wa_walk_fast<MODE, ALPHA1>(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
+        wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, dirty, clean_info, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
     else if (st.len >= (int32_t)D.path_cap) {  // cannot happen after a replay (the best path fits), kept for symmetry
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
@@ -600,7 +624,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     } else if (!prefix_words && lane == 0) {
         path[0] = start;  // the slow loop reads the path back from memory
     }
-    if (!st.done) wa_walk_slow<MODE>(D, R, pher, heur, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
+    if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, dirty, clean_info, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
@@ -639,6 +663,10 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
     const int32_t dk = wa_delta(kk, D.d.nx, D.d.nxy);
     const int32_t last_id = (int32_t)D.d.n - 1;
+    // lazy evaporation: a best-path node that never received a deposit (possible when no rank deposits at all)
+    // holds the clean value of the field as it stands now, i.e. after this generation's evaporation
+    const uint8_t *dirty = D.dirty ? D.dirty + (int64_t)slot * D.dirty_stride : nullptr;
+    const float clean_now = ctl->clean[ctl->gen & 1];
     for (int32_t i = row0; i < blen; i += rows) {
         const int32_t wv = i == row0 ? w_first : bpath[i];
         const int32_t wn = i + 1 < blen ? (i == row0 ? w_first_next : bpath[i + 1]) : 0;
@@ -647,6 +675,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
         const int64_t e = (int64_t)v * 6 + kk;
         float p = pher[e];
         const float h = heur[e];
+        if (dirty && !dirty[v]) p = copysignf(clean_now, p);
         unsigned long long m = apply_here ? mask[e] : 0ULL;
         const uint32_t bt = btabu[i];
         int32_t nbid = v + dk;
@@ -700,6 +729,8 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
     // last launch of a captured graph of `advance` generations: move the device generation counter on (no block of
     // this launch reads it; the next launch is ordered after this one)
     if (advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *D.genbase += advance;
+    // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
+    if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
     if ((int32_t)blockIdx.x < WA_TABLE_BLOCKS) {
         // independent loads first: deposit coefficients, control block, this row's path words
         const int32_t tid = threadIdx.x, row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -717,7 +748,7 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
-template <bool ALPHA1>
+template <bool ALPHA1, bool SPARSE>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen_off)
 {
     extern __shared__ int32_t lds[];
@@ -730,7 +761,8 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     int32_t f = 0, b = 0;
     const float bestL = c->bestL;
     const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
-    wa_walk_one<1, ALPHA1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL);
+    wa_walk_one<1, ALPHA1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
+                                   c->clean[gen & 1]);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -749,7 +781,7 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY);
+        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
@@ -1087,6 +1119,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // PUBLISHES what k_rank publishes (global best, perm/depA for the apply pass, trace, the next
 // generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
                                                         float *dst_base, int32_t E, int32_t gen_off)
 {
@@ -1094,8 +1127,23 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
     // their latency-bound work hides under the sweep blocks that follow
     if ((int32_t)blockIdx.x >= 512) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
-        wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
-                      (int32_t)blockIdx.x - 512, E);
+        if (!SPARSE) {
+            wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
+                          (int32_t)blockIdx.x - 512, E);
+        } else {
+            // lazy evaporation: only the records of voxels that ever received a deposit are swept (in place); the
+            // voxels that become dirty during THIS launch are written at their post-evaporation value by the
+            // mark blocks below and sit past n0 in the list, so the two roles touch disjoint records
+            float *ph = dst_base + (int64_t)slot * D.pher_stride;
+            const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
+            const int32_t n0 = D.dcount[slot * 2];
+            const float rho = R.rho;
+            for (int64_t q = (int64_t)((int32_t)blockIdx.x - 512) * blockDim.x + tid; q < (int64_t)n0 * 6; q += (int64_t)E * blockDim.x) {
+                const int32_t v = list[q / 6];
+                const int64_t e = (int64_t)v * 6 + (q % 6);
+                ph[e] = ph[e] * rho;
+            }
+        }
         return;
     }
     // ---- rank + mark
@@ -1185,6 +1233,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             c.dep_bestL = bestL;
             c.n_dep = n_dep;
             c.gen = gen + 1;
+            c.clean[(gen + 1) & 1] = c.clean[gen & 1] * R.rho;   // what one more evaporation makes of a never-deposited edge
             wa_next_params(c, R, (gen + 1) & 1);
             *ctl = c;  // nothing a sibling block reads during this launch changes: [gen&1] slots, start/end/stream
         }
@@ -1196,11 +1245,27 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const int32_t len = antLen[a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    float *ph = dst_base + (int64_t)slot * D.pher_stride;
+    const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
     for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += 8 * blockDim.x) {
         int32_t w = path[i];
         int32_t v = path[i - 1] & WaNbT<6>::IDM;
         int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WaNbT<6>::SHIFT);
         atomicOr(&mask[e], 1ULL << bit);
+        if (SPARSE) {   // first deposit ever on an edge leaving v: v joins the swept set, its record is materialised
+            uint32_t *dw = reinterpret_cast<uint32_t *>(D.dirty + (int64_t)slot * D.dirty_stride) + (v >> 2);
+            const uint32_t sh = (uint32_t)(v & 3) * 8u;
+            const uint32_t old = atomicOr(dw, 1u << sh);
+            if (((old >> sh) & 0xffu) == 0) {
+                const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
+                D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
+                    const float st0 = ph[(int64_t)v * 6 + k];
+                    ph[(int64_t)v * 6 + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
+                }
+            }
+        }
     }
 }
 
@@ -1297,6 +1362,55 @@ __global__ __launch_bounds__(256) void k_deposit_apply(WaAcsDev D, int32_t base)
 {
     __shared__ float s_dep_[64];
     wa_apply_body<NB>(D, blockIdx.z, base, blockIdx.y, blockIdx.x, gridDim.x, false, s_dep_);
+}
+
+// ------------------------------------------------------------------ lazy evaporation: reset / read-back helpers
+// after k_init_pheromone (every record holds its init value): nothing is dirty, the clean value is p0
+__global__ void k_lazy_clear(WaAcsDev D, int32_t slot0, int32_t cnt, float p0)
+{
+    const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= cnt) return;
+    const int32_t slot = slot0 + q;
+    D.dcount[slot * 2] = 0;
+    D.dcount[slot * 2 + 1] = 0;
+    D.ctl[slot].clean[0] = p0;
+    D.ctl[slot].clean[1] = p0;
+}
+// reset() of a lazy slot whose init mode and p0 are unchanged: only the dirty records are rewritten
+// (same values as k_init_pheromone) and their flags cleared.  grid.y = slots.
+__global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
+{
+    const int32_t slot = slot0 + blockIdx.y;
+    const int32_t n = D.dcount[slot * 2 + 1];
+    const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
+    uint8_t *dirty = D.dirty + (int64_t)slot * D.dirty_stride;
+    float *ph = D.pher + (int64_t)slot * D.pher_stride;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int32_t id = list[q];
+        const int32_t x = id % D.d.nx, y = (id / D.d.nx) % D.d.ny, z = id / D.d.nxy;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
+                          Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
+            const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
+            const bool adm = inb && D.occ[id + wa_delta(k, D.d.nx, D.d.nxy)] != 0;
+            const float v = (inb || mode == 1) ? p0 : 0.f;
+            ph[(int64_t)id * 6 + k] = adm ? v : -v;
+        }
+        dirty[id] = 0;
+    }
+}
+// the field as the dense sweep would have left it: dirty records as stored, clean records at the clean value
+__global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, int32_t slot, float *out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= D.d.n * 6) return;
+    const int64_t v = e / 6;
+    const float st0 = D.pher[(int64_t)slot * D.pher_stride + e];
+    const WaSlotCtl *c = &D.ctl[slot];
+    const float clean = c->clean[c->gen & 1];
+    const bool is_dirty = D.dirty[(int64_t)slot * D.dirty_stride + v] != 0;
+    out[e] = is_dirty ? fabsf(st0) : (fabsf(st0) == 0.f ? 0.f : clean);
 }
 
 // =====================================================================================================

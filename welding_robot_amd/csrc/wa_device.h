@@ -50,6 +50,9 @@ struct WaSlotCtl {
     float dep_lambda, dep_Q, dep_bestL;
     int32_t n_dep;          // ranks 1..n_dep deposit             (:200)
     int32_t flags;
+    // lazy evaporation (wa_acs_create_lazy): the value every never-deposited in-bounds edge holds after the
+    // evaporations so far, pheromone_0 * rho * rho * ... in the reference's own fp32 rounding; slot [g & 1] like the others
+    float clean[2];
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index

@@ -59,6 +59,9 @@ struct wa_acs {
     int cur_buf;
     WaRun R;
     bool begun, overlap_walk, overlap_rank, fuse, inplace, fuse_table;
+    bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
+    std::vector<int> lazy_mode;         // per slot: init mode of the stored records (-1 unknown)
+    std::vector<float> lazy_p0;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     // hipGraph of `graph_len` generations of the fused DEV loop (0 = off), valid for the run begun last
     int32_t graph_len, graph_buf0, genbase_host;
@@ -380,7 +383,7 @@ void wa_acs_default_params(wa_acs_params *p)
 
 
 static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
-                      int64_t path_capacity, int32_t nb, wa_acs **out)
+                      int64_t path_capacity, int32_t nb, bool lazy, wa_acs **out)
 {
     if (!ctx || !grid || !out || n_slots < 1 || max_colony < 1) return fail(ctx, WA_ERR_ARG, "wa_acs_create: bad argument");
     *out = nullptr;
@@ -403,6 +406,9 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     const int64_t n = grid->d.n;
     if (nb != 6 && nb != 26) { delete s; return fail(ctx, WA_ERR_ARG, "wa_acs_create: neighbourhood must be 6 or 26"); }
     s->nb = nb;
+    s->lazy = lazy;
+    s->lazy_mode.assign(n_slots, -1);
+    s->lazy_p0.assign(n_slots, 0.f);
     if (nb == 6 && 24 * n >= (int64_t)1 << 31) {  // the walk addresses a slot's pheromone field with signed 32-bit byte offsets
         delete s;
         return fail(ctx, WA_ERR_ARG, "wa_acs_create: grids above 89,478,485 voxels (~447^3) are not supported");
@@ -441,21 +447,28 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     s->fuse = env_int("WA_FUSE", 1) != 0;
     s->fuse_table = env_int("WA_FUSE_TABLE", 1) != 0;
     s->inplace = env_int("WA_EVAP_INPLACE", 0) != 0 && !s->overlap_walk;
-    s->graph_len = env_int("WA_GRAPH", 0) & ~1;   // even: the pheromone double buffer is back where it started
+    if (lazy) { s->fuse = s->fuse_table = true; s->overlap_walk = s->overlap_rank = s->inplace = false; }   // one loop shape only
+    s->graph_len = lazy ? 0 : env_int("WA_GRAPH", 0) & ~1;   // even: the pheromone double buffer is back where it started
     s->graph = nullptr;
     s->graph_exec = nullptr;
     s->genbase_host = 0;
     const size_t S = (size_t)n_slots, C = (size_t)max_colony;
     hipError_t e = hipSuccess;
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
-    e = e ? e : dalloc(&s->pher_buf[1], S * D.pher_stride);
+    if (!lazy) e = e ? e : dalloc(&s->pher_buf[1], S * D.pher_stride);   // the lazy sweep is in place: one field
+    if (lazy) {
+        D.dirty_stride = ((n + 3) / 4) * 4;
+        e = e ? e : dalloc(&D.dirty, S * D.dirty_stride);
+        e = e ? e : dalloc(&D.dirty_list, S * n);
+        e = e ? e : dalloc(&D.dcount, S * 2);
+    }
     e = e ? e : dalloc(&D.heur, S * D.pher_stride);
     e = e ? e : dalloc(&D.mask, S * D.pher_stride);
     e = e ? e : dalloc(&D.bestmark, S * n);
     e = e ? e : dalloc(&D.bestpath, S * path_capacity);
     e = e ? e : dalloc(&D.bestpos, S * n);
     e = e ? e : dalloc(&D.besttabu, S * path_capacity);
-    if (env_int("WA_REPLAY", 1) != 0)   // replay table: 8 floats per best-path node (6 neighbours) / 32 (26 neighbours)
+    if (lazy || env_int("WA_REPLAY", 1) != 0)   // replay table: 8 floats per best-path node (6 neighbours) / 32 (26 neighbours)
         e = e ? e : dalloc(&D.rtab, S * path_capacity * (nb == 6 ? 8 : WA_ROW26) + 256);
     e = e ? e : dalloc(&D.paths, S * C * path_capacity);
     e = e ? e : dalloc(&D.antL, S * C);
@@ -480,7 +493,11 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     D.pher = s->pher_buf[0];
     s->cur_buf = 0;
     HIPC(ctx, hipMemsetAsync(s->pher_buf[0], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
-    HIPC(ctx, hipMemsetAsync(s->pher_buf[1], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    if (s->pher_buf[1]) HIPC(ctx, hipMemsetAsync(s->pher_buf[1], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
+    if (lazy) {
+        HIPC(ctx, hipMemsetAsync(D.dirty, 0, S * D.dirty_stride, ctx->stream));
+        HIPC(ctx, hipMemsetAsync(D.dcount, 0, sizeof(int32_t) * S * 2, ctx->stream));
+    }
     HIPC(ctx, hipMemsetAsync(D.bestmark, 0, sizeof(uint32_t) * S * n, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.vbits, 0, sizeof(uint32_t) * S * C * D.vbits_words, ctx->stream));
     HIPC(ctx, hipMemsetAsync(D.ctl, 0, sizeof(WaSlotCtl) * S, ctx->stream));
@@ -499,12 +516,17 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
 int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity,
                   wa_acs **out)
 {
-    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, 6, out);
+    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, 6, false, out);
 }
 int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity,
                      int32_t neighbourhood, wa_acs **out)
 {
-    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, neighbourhood, out);
+    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, neighbourhood, false, out);
+}
+int wa_acs_create_lazy(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity,
+                       wa_acs **out)
+{
+    return acs_create(ctx, grid, n_slots, max_colony, path_capacity, 6, true, out);
 }
 
 static void free_trace(wa_acs *s)
@@ -526,6 +548,7 @@ void wa_acs_destroy(wa_acs *s)
     hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.besttabu); hipFree(D.rtab);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
     hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg); hipFree(D.genbase);
+    hipFree(D.dirty); hipFree(D.dirty_list); hipFree(D.dcount);
     if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
     if (s->graph) hipGraphDestroy(s->graph);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
@@ -541,6 +564,23 @@ static int init_pher(wa_acs *s, int32_t slot, float p0, int mode)
         dim3 grid26((unsigned)((s->D.d.n * 26 + 255) / 256), (unsigned)cnt);
         k_init_pheromone26<<<grid26, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
         HIPC(s->ctx, hipGetLastError());
+        return WA_OK;
+    }
+    if (s->lazy) {
+        // same init mode and p0 as the records already hold: rewrite the dirty records only (reset() between pair
+        // searches costs O(deposited voxels) instead of a 24-B/voxel pass); otherwise the full pass
+        bool same = true;
+        for (int32_t q = slot0; q < slot0 + cnt; q++) same = same && s->lazy_mode[q] == mode && s->lazy_p0[q] == p0;
+        if (same) {
+            k_lazy_restore<<<dim3(64, (unsigned)cnt), 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
+        } else {
+            dim3 gridf((unsigned)((s->D.d.n + 255) / 256), (unsigned)cnt);
+            k_init_pheromone<<<gridf, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
+            HIPC(s->ctx, hipMemsetAsync(s->D.dirty + (int64_t)slot0 * s->D.dirty_stride, 0, (size_t)cnt * s->D.dirty_stride, s->ctx->stream));
+        }
+        k_lazy_clear<<<(cnt + 63) / 64, 64, 0, s->ctx->stream>>>(s->D, slot0, cnt, p0);
+        HIPC(s->ctx, hipGetLastError());
+        for (int32_t q = slot0; q < slot0 + cnt; q++) { s->lazy_mode[q] = mode; s->lazy_p0[q] = p0; }
         return WA_OK;
     }
     dim3 grid((unsigned)((s->D.d.n + 255) / 256), (unsigned)cnt);
@@ -603,6 +643,8 @@ int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
     int32_t bound = p->fixed_colony > 0 ? p->fixed_colony : (int32_t)(0.35 * (double)p->predict / (double)R.precision);
     if (bound > s->max_colony) return fail(ctx, WA_ERR_CAPACITY, "wa_acs_begin: colony exceeds max_colony of the solver");
     s->colony_bound = bound < 0 ? 0 : bound;
+    if (s->lazy && (p->rng_mode != WA_RNG_DEV || s->colony_bound > WA_RANK_LDS || (int32_t)(0.2 * s->colony_bound) + 1 > 64 || !s->D.rtab))
+        return fail(ctx, WA_ERR_ARG, "wa_acs_begin: a lazily evaporating solver runs the fused DEV loop only (DEV mode, <= 2048 ants, <= 64 depositing ranks)");
     if (p->max_iteration > s->D.trace_cap) {
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
         free_trace(s);
@@ -679,13 +721,31 @@ static void launch_evaporate(wa_acs *s, hipStream_t st, const float *src, float 
 // the fused post-walk launch (sweep + rank + mark), timed per dispatch when sampled
 static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int32_t gen_off, bool timed)
 {
+    if (s->lazy) {   // sparse sweep of the deposited voxels + rank + mark (which also enrols newly deposited voxels)
+        const int32_t E = env_int("WA_LAZY_BLOCKS", 2048);   // grid-stride over the dirty list; surplus blocks exit at once
+        dim3 lgrid((unsigned)(E + 512), (unsigned)P);
+        if (timed) {
+            EvPair p;
+            p.cls = WA_K_EVAPORATE;
+            if (hipEventCreate(&p.a) == hipSuccess) {
+                if (hipEventCreate(&p.b) == hipSuccess) {
+                    hipExtLaunchKernelGGL(k_evap_rank_mark<true>, lgrid, dim3(256), 0, s->ctx->stream, p.a, p.b, 0, s->D, s->R, src, dst, E, gen_off);
+                    s->ev.push_back(p);
+                    return;
+                }
+                hipEventDestroy(p.a);
+            }
+        }
+        k_evap_rank_mark<true><<<lgrid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, E, gen_off);
+        return;
+    }
     dim3 grid((unsigned)(s->evap_blocks + 512), (unsigned)P);
     if (timed) {
         EvPair p;
         p.cls = WA_K_EVAPORATE;
         if (hipEventCreate(&p.a) == hipSuccess) {
             if (hipEventCreate(&p.b) == hipSuccess) {
-                hipExtLaunchKernelGGL(k_evap_rank_mark, grid, dim3(256), 0, s->ctx->stream, p.a, p.b, 0, s->D, s->R, src, dst,
+                hipExtLaunchKernelGGL(k_evap_rank_mark<false>, grid, dim3(256), 0, s->ctx->stream, p.a, p.b, 0, s->D, s->R, src, dst,
                                       s->evap_blocks, gen_off);
                 s->ev.push_back(p);
                 return;
@@ -693,7 +753,7 @@ static void launch_fused(wa_acs *s, const float *src, float *dst, int32_t P, int
             hipEventDestroy(p.a);
         }
     }
-    k_evap_rank_mark<<<grid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, s->evap_blocks, gen_off);
+    k_evap_rank_mark<false><<<grid, 256, 0, s->ctx->stream>>>(s->D, s->R, src, dst, s->evap_blocks, gen_off);
 }
 
 // One generation = walk -> rank -> evaporate -> deposit (ACSRank_3D.hpp:252-280), enqueued on one
@@ -713,21 +773,27 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
     const size_t shmem = sizeof(int32_t) << s->hash_log2;
     const int32_t dep_bound = (int32_t)(0.2 * s->colony_bound) + 1;
     const int32_t chunks = (dep_bound + 63) / 64;
-    const bool fused = s->nb == 6 && s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
+    const bool fused = s->lazy || s->nb == 6 && s->fuse && s->R.rng_mode == WA_RNG_DEV && s->colony_bound <= WA_RANK_LDS && dep_bound <= 64 &&
                        !s->overlap_walk && !s->overlap_rank;
     // One generation of the fused DEV loop: walk -> {sweep + rank + mark} -> {apply + replay table}.  gen_off is
     // relative to the device generation counter; advance != 0 on the last generation of a captured graph.
     auto enqueue_fused = [&](int32_t gen_off, int32_t advance, bool sampled) {
-        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (s->inplace ? 0 : 1)];
+        const bool one_buf = s->inplace || s->lazy;
+        float *src = s->pher_buf[s->cur_buf], *dst = s->pher_buf[s->cur_buf ^ (one_buf ? 0 : 1)];
         EvPair *e = prof_open(s, WA_K_WALK, sampled);
         if (s->colony_bound > 0) {
             dim3 wg((unsigned)s->colony_bound, (unsigned)P);
-            if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
-            else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+            if (s->lazy) {
+                if (s->R.alpha == 1) k_walk_dev<true, true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+                else k_walk_dev<false, true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+            } else {
+                if (s->R.alpha == 1) k_walk_dev<true, false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+                else k_walk_dev<false, false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen_off);
+            }
         }
         prof_close(s, e);
         launch_fused(s, src, dst, P, gen_off, sampled);
-        if (!s->inplace) s->cur_buf ^= 1;
+        if (!one_buf) s->cur_buf ^= 1;
         s->D.pher = dst;
         e = prof_open(s, WA_K_DEPOSIT, sampled);
         if (s->D.rtab && s->fuse_table) {
@@ -792,8 +858,8 @@ int wa_acs_run(wa_acs *s, int32_t n_generations)
         } else if (s->R.rng_mode == WA_RNG_DEV) {
             if (s->colony_bound > 0) {
                 dim3 wg((unsigned)s->colony_bound, (unsigned)P);
-                if (s->R.alpha == 1) k_walk_dev<true><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
-                else k_walk_dev<false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
+                if (s->R.alpha == 1) k_walk_dev<true, false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
+                else k_walk_dev<false, false><<<wg, 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen - s->genbase_host);
             }
         } else {
             k_walk_ref<<<dim3(1, 1), 64, shmem, ctx->stream>>>(s->D, s->R, s->hash_log2, gen);
@@ -939,6 +1005,16 @@ int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out)
     wa_ctx *ctx = s->ctx;
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t m = (int64_t)s->nb * s->D.d.n;
+    if (s->lazy) {   // the field as the dense sweep would have left it
+        float *d_out = nullptr;
+        if (dalloc(&d_out, (size_t)m)) return fail(ctx, WA_ERR_ALLOC, "wa_acs_read_pheromone: staging");
+        k_lazy_materialise<<<(unsigned)((m + 255) / 256), 256, 0, ctx->stream>>>(s->D, slot, d_out);
+        hipError_t h = hipGetLastError();
+        h = h ? h : hipMemcpy(out, d_out, sizeof(float) * m, hipMemcpyDeviceToHost);
+        hipFree(d_out);
+        if (h != hipSuccess) return fail(ctx, WA_ERR_DEVICE, "wa_acs_read_pheromone: %s", hipGetErrorString(h));
+        return WA_OK;
+    }
     HIPC(ctx, hipMemcpy(out, s->D.pher + (int64_t)slot * s->D.pher_stride, sizeof(float) * m, hipMemcpyDeviceToHost));
     uint32_t *u = (uint32_t *)out;
     for (int64_t i = 0; i < m; i++) u[i] &= 0x7fffffffu;  // drop the admissibility bit
@@ -989,6 +1065,7 @@ int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset)
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats)
 {
     if (!s || slot < 0 || slot >= s->n_slots || repeats < 1) return WA_ERR_ARG;
+    if (s->lazy) return fail(s->ctx, WA_ERR_STATE, "wa_acs_evaporate: this solver evaporates lazily (no dense sweep to run)");
     // same out-of-place sweep as the generation loop; all slots flip together, so the other
     // slots are carried across with rho = 1 (exact copy)
     for (int32_t r = 0; r < repeats; r++) {

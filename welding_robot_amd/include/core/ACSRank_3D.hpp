@@ -12,6 +12,8 @@
 //   setMaxIteration(n)    default 150 (:322)      setFixedColony(n)  0 = reference-adaptive (:247)
 //   setNeighbourhood(n)   6 (default, the reference as shipped) or 26: the reference's own stubbed variant with
 //                         edge/corner moves of length precision*1.414f / precision*1.732f (:361-388)
+//   setLazyEvaporation(b) default true: DEV-mode pair searches use wa_acs_create_lazy (never-deposited voxels are not
+//                         swept; identical results, a generation costs O(deposited voxels) instead of 48 B/voxel)
 //   setGraphFileCompat(b) true = reproduce the reference's damaged graph.in header (Q6); default writes
 //                         a correct file.  The cost matrix is always also kept in memory: cost_matrix().
 #ifndef _ACS_3D_HPP
@@ -116,6 +118,7 @@ public:
     void setMaxIteration(int n) { max_iteration = n; }
     void setFixedColony(int n) { fixed_colony = n; }
     void setNeighbourhood(int n) { neighbourhood = n; }
+    void setLazyEvaporation(bool b) { lazy = b; }
     void setGraphFileCompat(bool b) { graph_compat = b; }
     void setConcurrentPairs(int n) { concurrent_pairs = n; }
     int lastStatus() const { return last_status; }
@@ -276,6 +279,7 @@ private:
     wa_acs *solver = NULL;
     int slots = 1;
     int rng_mode = WA_RNG_DEV, max_iteration = 150, fixed_colony = 0, concurrent_pairs = 16, neighbourhood = 6;
+    bool lazy = true;
     uint64_t seed = 1;
     bool seeded = false, graph_compat = false;
     int last_status = WA_OK;
@@ -296,7 +300,9 @@ private:
         int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
         if (colony < 1) colony = 1;
         slots = rng_mode == WA_RNG_REF ? 1 : std::max(1, concurrent_pairs);
-        int rc = wa_acs_create_nb(ctx, device_grid(), slots, colony, 0, neighbourhood, &solver);
+        const bool lazy_ok = lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64;
+        int rc = lazy_ok ? wa_acs_create_lazy(ctx, device_grid(), slots, colony, 0, &solver)
+                         : wa_acs_create_nb(ctx, device_grid(), slots, colony, 0, neighbourhood, &solver);
         if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(ctx)); last_status = rc; return false; }
         wa_acs_init_pheromone(solver, -1, 1.0f);
         if (rng_mode == WA_RNG_REF) wa_acs_srand(solver, (uint32_t)seed);
