@@ -453,6 +453,8 @@ def test_batched_pair_planning_matches_oracle_and_is_shard_invariant(ctx):
     c0, _, n0 = pb.plan(ctx, dg, pts, gens, predict, seed, slots=3, rank=0, world=2)
     c1, _, n1 = pb.plan(ctx, dg, pts, gens, predict, seed, slots=5, rank=1, world=2)
     assert n0 + n1 == len(pairs) and np.array_equal(c0 + c1, cost)  # the SUM all-reduce of the two shards
+    cl, pl, _ = pb.plan(ctx, dg, pts, gens, predict, seed, slots=4, lazy=True)   # lazy evaporation: same matrix, same paths
+    assert np.array_equal(cl, cost) and all(np.array_equal(pl[k], paths[k]) for k in paths)
     assert np.isfinite(cost).all()
     t = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=seed)
     o = O.gtsp_solve(cost, mode=O.DEV, seed=seed)
