@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-gens", type=int, default=20, help="generations of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary C5-shaped pair-planning measurement")
     ap.add_argument("--workload-index", type=int, default=None,
                     help="run rank R's C4 workload (grid seed 2024+R, colony seed 12345+R) on this GPU; default = own rank")
     return ap.parse_args()
@@ -86,6 +87,34 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
             return out
     out["cpu_baseline"] = {"value": port_rate, "unit": "generations/s", "cores": 1, "kind": "port", "sample": sample}
     return out
+
+
+def pair_planning_extra(ctx, grid, free, n):
+    """Secondary, informational: BASELINE config C5's shape on the bench grid -- all pair searches between 16 weld
+    points (120 pairs x 150 generations, 24 ants each, 32 concurrent slots) with the dense sweep and with lazy
+    evaporation (wa_acs_create_lazy); the two must agree bit for bit.  Not part of `value`."""
+    import importlib.util
+    import numpy as np
+    from welding_robot_amd import synth
+    spec = importlib.util.spec_from_file_location("plan_batch", os.path.join(ROOT, "examples", "plan_batch.py"))
+    pb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pb)
+    pts = synth.synth_weld_points(free, n, 16, seed=7)
+    gens, predict = 150, float(24 / 0.35)
+    res = {}
+    for lazy in (False, True):
+        pb.plan(ctx, grid, pts[:4], 5, predict, 7, 8, lazy=lazy)      # warm-up (allocation, first launches)
+        ctx.sync()
+        t0 = time.perf_counter()
+        cost, paths, _ = pb.plan(ctx, grid, pts, gens, predict, 7, 32, lazy=lazy)
+        ctx.sync()
+        res[lazy] = (time.perf_counter() - t0, cost, paths)
+    same = bool(np.array_equal(res[False][1], res[True][1]) and all(np.array_equal(res[False][2][k], res[True][2][k]) for k in res[False][2]))
+    pairs = len(pts) * (len(pts) - 1) // 2
+    return {"workload": "%d^3 grid, 16 weld points = %d pair searches x %d generations, 24 ants, 32 slots" % (n, pairs, gens),
+            "dense_sweep_pair_generations_per_s": pairs * gens / res[False][0],
+            "lazy_evaporation_pair_generations_per_s": pairs * gens / res[True][0],
+            "identical_costs_and_paths": same}
 
 
 def main():
@@ -225,6 +254,8 @@ def main():
             solver.sync()
             gpu_first_ms = (time.perf_counter() - t1) * 1e3
             out.update(cpu_baseline(args, free, n, trace, gpu_first_ms))
+        if world == 1 and not args.no_extras:
+            out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
