@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
     const double INF = (double)0x3f3f3f3f;  // ACS_GTSP.hpp:19
     const double alpha = 0.1;               // :189
     __shared__ double s_L[256];
+    __shared__ int32_t s_tour[256];    // the iteration-best tour, staged for the deposit
+    __shared__ uint8_t s_valid[256];   // ant k's tour visits every city exactly once
     __shared__ double s_pher0, s_bestL, s_last, s_nowL;
     __shared__ int32_t s_bad, s_nowk, s_stop, s_it;
     if (tid == 0) {
@@ -248,7 +250,6 @@ __global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
             for (int w = 0; w < NW; w++)
                 if ((k >> 6) == w) J[w] &= ~(1ULL << (k & 63));  // J[i].erase(r1[i]) :111
             int32_t r = k, left = n - 1;
-            double L = 0;
             for (int32_t step = 0; step < n; step++) {
                 int32_t next = k;  // r1[k]
                 if (left > 0) {    // select_next :122-144
@@ -301,10 +302,19 @@ __global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
                         if (J[w] & bit) { J[w] &= ~bit; left--; }  // J[k].erase(next) :153
                     }
                 tours[(int64_t)k * n + step] = next;
-                if (step < n - 1) L += r == next ? 0.0 : dist[(int64_t)r * n + next];  // calc :36-44
                 r = next;
             }
+            // tour length (calc :36-44) after the walk: the same in-order fp64 sum, but its distance loads no longer
+            // sit one global round trip deep inside every construction step
+            double L = 0;
+            r = k;
+            for (int32_t step = 0; step < n - 1; step++) {
+                const int32_t nx2 = tours[(int64_t)k * n + step];
+                L += r == nx2 ? 0.0 : dist[(int64_t)r * n + nx2];
+                r = nx2;
+            }
             s_L[k] = L;
+            s_valid[k] = left == 0 ? 1 : 0;
         }
         __syncthreads();
         if (tid == 0) {  // update_pheromone :163-174: first strictly smallest tour
@@ -323,16 +333,33 @@ __global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
                 best[2 * e + 1] = tours[(int64_t)nowk * n + e];
             }
         for (int64_t e = tid; e < nn; e += blockDim.x) pher[e] *= (1 - alpha);  // :175-177
+        if (nowk >= 0)
+            for (int32_t e = tid; e < n; e += blockDim.x) s_tour[e] = tours[(int64_t)nowk * n + e];
+        __syncthreads();
+        // deposit :179-184 on all n edges incl. the closing one.  A tour that visits every city once has n distinct
+        // undirected edges (n >= 3), each receiving exactly one add: order-free, so one lane per edge.  A degenerate
+        // tour (a step found no candidate and fell back to the start city) may repeat an edge: sequential as written.
+        const bool par_deposit = nowk >= 0 && n >= 3 && s_valid[nowk];
+        if (par_deposit) {
+            for (int32_t e = tid; e < n; e += blockDim.x) {
+                const int32_t a = e == 0 ? nowk : s_tour[e - 1], b = s_tour[e];
+                const double pv = pher[(int64_t)a * n + b] + 1. / (double)s_nowL;
+                pher[(int64_t)a * n + b] = pv;
+                pher[(int64_t)b * n + a] = pv;
+            }
+        }
         __syncthreads();
         if (tid == 0) {
             if (nowk >= 0) {
                 if (s_nowL < s_bestL) s_bestL = s_nowL;
-                int32_t a = nowk;
-                for (int32_t e = 0; e < n; e++) {  // :179-184, all n edges incl. the closing one
-                    const int32_t b = tours[(int64_t)nowk * n + e];
-                    pher[(int64_t)a * n + b] += 1. / (double)s_nowL;
-                    pher[(int64_t)b * n + a] = pher[(int64_t)a * n + b];
-                    a = b;
+                if (!par_deposit) {
+                    int32_t a = nowk;
+                    for (int32_t e = 0; e < n; e++) {
+                        const int32_t b = s_tour[e];
+                        pher[(int64_t)a * n + b] += 1. / (double)s_nowL;
+                        pher[(int64_t)b * n + a] = pher[(int64_t)a * n + b];
+                        a = b;
+                    }
                 }
             }
             if (s_last > s_bestL) { s_last = s_bestL; s_bad = 0; }
