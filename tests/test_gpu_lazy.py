@@ -120,6 +120,22 @@ def test_lazy_init_then_reset_switches_mode(ctx):
         assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), step
 
 
+def test_lazy_rho_change_and_long_carry_over(ctx):
+    """Consecutive solves WITHOUT reset, with different rho and odd generation counts: the pending evaporations of
+    deposited records (at most 16 are ever outstanding) are applied with the rho they belong to."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    sid, eid = og.resolve(og.node_pt(4, 4, 4)), og.resolve(og.node_pt(20, 27, 20))
+    s = api.AcsSolver(ctx, dg, 1, 16, lazy=True)
+    a = O.Acs(og)
+    for rnd, (rho, gens) in enumerate([(0.8, 37), (0.9, 21), (0.9, 18), (0.5, 5), (0.8, 64)]):
+        p = api.default_params(max_iteration=gens, predict=1.03, fixed_colony=16, rng_mode=api.RNG_DEV, seed=3 + rnd, rho=rho)
+        s.solve(p, sid, eid)
+        a.solve(sid, eid, gens, 1.03, fixed_colony=16, mode=O.DEV, seed=3 + rnd, rho=rho)
+        assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), rnd
+        assert np.array_equal(s.result()[1], a.best_path()[0])
+
+
 def test_lazy_stepwise_runs(ctx):
     og = O.synth_grid(24, seed=3, occ_prob=0.12)
     dg = dgrid_from(ctx, og)

@@ -44,13 +44,16 @@ struct WaAcsDev {
     int32_t max_colony;
     int32_t trace_cap;
     int32_t nb;                    // edges per voxel: 6 (face neighbours) or 26 (faces + edges + corners)
-    // lazy evaporation: a voxel whose six outgoing edges never received a deposit ("clean") is not swept; its edges
-    // are worth ctl.clean (or 0 where the stored value is 0).  dirty = one byte per voxel, dirty_list = the swept set,
-    // dcount[slot][2] = {entries swept by the next sweep, append cursor}.  All null in the (default) dense mode.
-    uint8_t *dirty;                // [slot][n4] (n rounded up to 4)
+    // lazy evaporation: a voxel whose six outgoing edges never received a deposit ("clean", stamp 0) is never swept; its
+    // edges are worth ctl.clean (or 0 where the stored value is 0).  A deposited ("dirty") voxel carries
+    // stamp = 1 + the evaporation count its stored record is current for; whoever needs the record later applies the
+    // missing multiplications by rho one by one (same fp32 roundings as the sweep).  Records are brought current when
+    // they receive a deposit, and every WA_LAZY_PERIOD generations by a background pass over 1/WA_LAZY_PERIOD of the
+    // dirty list, so at most WA_LAZY_PERIOD multiplications are ever pending.  dcount[slot][2] = {list entries the
+    // background pass may touch, append cursor}.  All null in the (default) dense mode.
+    uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
-    int64_t dirty_stride;
     int32_t *genbase;              // device generation counter: kernels of the fused DEV loop run generation *genbase + gen_off,
                                    // which lets a captured hipGraph of G generations be replayed (the graph's last kernel adds G)
 };
@@ -136,6 +139,7 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.end = (int32_t)ends[slot];
     c.stream = streams ? streams[slot] : (uint32_t)slot;
     c.clean[0] = c.clean[c.gen & 1];   // lazy evaporation: the field's clean value carries over; generation parity restarts
+    c.evap_base += (uint32_t)c.gen;    // ... and so does the count of evaporations applied so far
     c.gen = 0;
     c.bestL = INFINITY;  // :232; the best PATH is kept (Q9) but unreachable while bestL is inf
     c.best_len = 0;
@@ -146,6 +150,14 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 __global__ void k_set_genbase(WaAcsDev D, int32_t v) { *D.genbase = v; }
+
+#define WA_LAZY_PERIOD 16
+// stored value -> value after `lag` more evaporations (:270, one rounding per multiplication like the sweep)
+__device__ __forceinline__ float wa_catch_up(float v, uint32_t lag, float rho)
+{
+    for (uint32_t i = 0; i < lag; i++) v *= rho;
+    return v;
+}
 
 // ------------------------------------------------------------------ the walk
 // One wavefront = one ant.  Lanes 0..5 own the six neighbours (edge order of :355-365); the
@@ -256,7 +268,8 @@ struct WaWalkState {
 // the wave flushes 64 consecutive path entries with ONE coalesced 256-byte store.
 template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__restrict__ pher,
-                                             const float *__restrict__ heur, const uint8_t *__restrict__ dirty, float clean_info,
+                                             const float *__restrict__ heur, const uint32_t *__restrict__ stamp, float clean_info,
+                                             uint32_t evap_now,
                                              int32_t *__restrict__ path,
                                              int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
                                              int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
@@ -294,7 +307,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     int grp = 0;             // group holding the record of `cur`
     float ublock = 0.f;      // DEV: lane i holds the uniform draw of the step with (len & 63) == i
     float pp = -0.f, ph = 0.f;
-    uint32_t pd = 1;         // SPARSE: dirty flag of the voxel whose record pp/ph belong to (clean => edges are worth clean_info)
+    uint32_t pd = 1;         // SPARSE: stamp of the voxel whose record pp/ph belong to (0 = clean => edges are worth clean_info)
     // software pipeline: the record of `cur` (pp/ph) and the tabu probe of its neighbours (tv/hs)
     // are issued one step early, right after `cur` became known, and consumed at the loop top
     int32_t nb = cur + dk;
@@ -305,7 +318,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         pp = *reinterpret_cast<const float *>(pher_b + boff);
         ph = *reinterpret_cast<const float *>(heur_b + boff);
     }
-    if (SPARSE) pd = dirty[cur];
+    if (SPARSE) pd = stamp[cur];
     tv = tab[hs];            // every lane probes (unmasked): only the active group's result is used
     if (MODE == 1) ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
     bool dead = false;
@@ -316,7 +329,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     for (;;) {
         WA_STAMP(0);                             // loop back-edge + wait for the prefetched record
         const float p = pp, h = ph;              // record of `cur`, valid in group `grp`
-        const uint32_t pdirty = pd;
+        const uint32_t pstamp = pd;
         // lane predicates are kept as 64-bit SCALAR masks (one v_cmp each, combined with s_and): a ballot of a
         // compound lane condition would round-trip through a VGPR (v_cndmask + v_cmp) every time it is tested
         const unsigned long long actm = 0x3fULL << (grp * 8);   // roles 0..5 of the active group
@@ -327,10 +340,10 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             asm("v_med3_i32 %0, %1, %2, %3" : "=v"(boff) : "v"(boff), "v"(pf_lo), "v"(pf_hi));
             pp = *reinterpret_cast<const float *>(pher_b + (uint32_t)boff);
             ph = *reinterpret_cast<const float *>(heur_b + (uint32_t)boff);
-            if (SPARSE) {                        // the neighbour's dirty byte travels with its record
+            if (SPARSE) {                        // the neighbour's stamp travels with its record
                 int32_t vj = cur + dj;
                 asm("v_med3_i32 %0, %1, %2, %3" : "=v"(vj) : "v"(vj), "v"(0), "v"(last_id));
-                pd = dirty[vj];
+                pd = stamp[vj];
             }
         }
         WA_STAMP(1);                             // prefetch issue
@@ -346,8 +359,14 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         WA_STAMP(2);                             // probe wait + collision check
         // in bounds and free (sign bit clear), not visited (:145-148)
         const unsigned long long admm = actm & __ballot((int32_t)__float_as_uint(p) >= 0) & __ballot(tv != nb);
-        float pa = ALPHA1 ? fabsf(p) : wa_powi(fabsf(p), R.alpha);
-        if (SPARSE) pa = pdirty ? pa : clean_info;                                // never-deposited voxel: every admissible edge holds the clean value
+        float mag = fabsf(p);
+        uint32_t stv = 1;
+        if (SPARSE) {   // the six lanes of the active group hold the same voxel's stamp: uniform, so scalar control flow
+            stv = (uint32_t)__builtin_amdgcn_readlane((int)pstamp, grp * 8);
+            if (stv != 0) mag = wa_catch_up(mag, evap_now + 1u - stv, R.rho);     // pending evaporations of a deposited voxel
+        }
+        float pa = ALPHA1 ? mag : wa_powi(mag, R.alpha);
+        if (SPARSE && stv == 0) pa = clean_info;                                  // never-deposited voxel: every admissible edge holds the clean value
         const float info = pa * h;                                                // :154
         float a;  // adm ? info : 0 -- x + 0.0f == x: padding keeps both sums exact
         asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(a) : "v"(info), "s"(admm));
@@ -418,7 +437,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
 template <int MODE, bool SPARSE>
 __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, const float *pher, const float *heur,
-                                          const uint8_t *dirty, float clean_info,
+                                          const uint32_t *stamp, float clean_info, uint32_t evap_now,
                                           int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t *rng_r,
                                           int32_t &rng_f, int32_t &rng_b, int32_t spill_at, WaWalkState &st,
                                           int32_t *flags_out)
@@ -449,8 +468,14 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
             h = heur[(int64_t)cur * 6 + k];
             if ((__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);
         }
-        float pa = wa_powi(fabsf(p), R.alpha);
-        if (SPARSE) pa = dirty[cur] ? pa : clean_info;
+        float mag = fabsf(p);
+        uint32_t stv = 1;
+        if (SPARSE) {
+            stv = stamp[cur];
+            if (stv != 0) mag = wa_catch_up(mag, evap_now + 1u - stv, R.rho);
+        }
+        float pa = wa_powi(mag, R.alpha);
+        if (SPARSE && stv == 0) pa = clean_info;
         float info = pa * h;
         uint32_t m = (uint32_t)__ballot(adm) & 0x3fu;
         if (m == 0) { L = INFINITY; break; }
@@ -559,12 +584,12 @@ template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
-                                            int32_t *flags_out, int32_t rlen, float bestL, float clean)
+                                            int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
-    const uint8_t *dirty = SPARSE ? D.dirty + (int64_t)slot * D.dirty_stride : nullptr;
+    const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
     const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
@@ -615,7 +640,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     __builtin_amdgcn_wave_barrier();
     const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
     if (st.len < fast_limit)
-        wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, dirty, clean_info, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
+        wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
     else if (st.len >= (int32_t)D.path_cap) {  // cannot happen after a replay (the best path fits), kept for symmetry
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
@@ -624,7 +649,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     } else if (!prefix_words && lane == 0) {
         path[0] = start;  // the slow loop reads the path back from memory
     }
-    if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, dirty, clean_info, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
+    if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
@@ -665,8 +690,10 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     const int32_t last_id = (int32_t)D.d.n - 1;
     // lazy evaporation: a best-path node that never received a deposit (possible when no rank deposits at all)
     // holds the clean value of the field as it stands now, i.e. after this generation's evaporation
-    const uint8_t *dirty = D.dirty ? D.dirty + (int64_t)slot * D.dirty_stride : nullptr;
+    // (and a deposited one that received nothing this generation may have evaporations pending: read-side catch-up)
+    const uint32_t *stamp = D.stamp ? D.stamp + (int64_t)slot * D.d.n : nullptr;
     const float clean_now = ctl->clean[ctl->gen & 1];
+    const uint32_t evap_tab = ctl->evap_base + (uint32_t)ctl->gen;   // the fused launch already counted this generation
     for (int32_t i = row0; i < blen; i += rows) {
         const int32_t wv = i == row0 ? w_first : bpath[i];
         const int32_t wn = i + 1 < blen ? (i == row0 ? w_first_next : bpath[i + 1]) : 0;
@@ -675,7 +702,10 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
         const int64_t e = (int64_t)v * 6 + kk;
         float p = pher[e];
         const float h = heur[e];
-        if (dirty && !dirty[v]) p = copysignf(clean_now, p);
+        if (stamp) {
+            const uint32_t stv = stamp[v];
+            p = stv == 0 ? copysignf(clean_now, p) : copysignf(wa_catch_up(fabsf(p), evap_tab + 1u - stv, R.rho), p);
+        }
         unsigned long long m = apply_here ? mask[e] : 0ULL;
         const uint32_t bt = btabu[i];
         int32_t nbid = v + dk;
@@ -762,7 +792,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const float bestL = c->bestL;
     const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
     wa_walk_one<1, ALPHA1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
-                                   c->clean[gen & 1]);
+                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -781,7 +811,7 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f);
+        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
@@ -1131,17 +1161,25 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
                           (int32_t)blockIdx.x - 512, E);
         } else {
-            // lazy evaporation: only the records of voxels that ever received a deposit are swept (in place); the
-            // voxels that become dirty during THIS launch are written at their post-evaporation value by the
-            // mark blocks below and sit past n0 in the list, so the two roles touch disjoint records
+            // lazy evaporation, background pass: every WA_LAZY_PERIOD-th entry of the dirty list (phase = generation)
+            // is brought current in place, so no record ever has more than WA_LAZY_PERIOD multiplications pending.
+            // A record is claimed by exchanging its stamp (the mark blocks of this launch claim the same way when a
+            // voxel receives a deposit), so exactly one thread applies the pending multiplications.
             float *ph = dst_base + (int64_t)slot * D.pher_stride;
             const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
+            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
             const int32_t n0 = D.dcount[slot * 2];
+            const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)(*D.genbase + gen_off);
+            const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
             const float rho = R.rho;
-            for (int64_t q = (int64_t)((int32_t)blockIdx.x - 512) * blockDim.x + tid; q < (int64_t)n0 * 6; q += (int64_t)E * blockDim.x) {
-                const int32_t v = list[q / 6];
-                const int64_t e = (int64_t)v * 6 + (q % 6);
-                ph[e] = ph[e] * rho;
+            const int64_t first = (int64_t)(evap_now % WA_LAZY_PERIOD);
+            for (int64_t q = first + (int64_t)WA_LAZY_PERIOD * ((int64_t)((int32_t)blockIdx.x - 512) * blockDim.x + tid); q < n0;
+                 q += (int64_t)WA_LAZY_PERIOD * E * blockDim.x) {
+                const int32_t v = list[q];
+                const uint32_t old = atomicExch(&stamp[v], target);
+                if (old == target) continue;
+#pragma unroll
+                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho);
             }
         }
         return;
@@ -1252,11 +1290,11 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         int32_t v = path[i - 1] & WaNbT<6>::IDM;
         int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WaNbT<6>::SHIFT);
         atomicOr(&mask[e], 1ULL << bit);
-        if (SPARSE) {   // first deposit ever on an edge leaving v: v joins the swept set, its record is materialised
-            uint32_t *dw = reinterpret_cast<uint32_t *>(D.dirty + (int64_t)slot * D.dirty_stride) + (v >> 2);
-            const uint32_t sh = (uint32_t)(v & 3) * 8u;
-            const uint32_t old = atomicOr(dw, 1u << sh);
-            if (((old >> sh) & 0xffu) == 0) {
+        if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
+            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
+            const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;
+            const uint32_t old = atomicExch(&stamp[v], target);
+            if (old == 0) {            // first deposit ever: v joins the dirty list, its record is written at the clean value
                 const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
                 D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
 #pragma unroll
@@ -1264,6 +1302,9 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
                     const float st0 = ph[(int64_t)v * 6 + k];
                     ph[(int64_t)v * 6 + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
                 }
+            } else if (old != target) {   // deposited before: apply the evaporations it has missed since
+#pragma unroll
+                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, R.rho);
             }
         }
     }
@@ -1375,6 +1416,8 @@ __global__ void k_lazy_clear(WaAcsDev D, int32_t slot0, int32_t cnt, float p0)
     D.dcount[slot * 2 + 1] = 0;
     D.ctl[slot].clean[0] = p0;
     D.ctl[slot].clean[1] = p0;
+    D.ctl[slot].evap_base = 0;
+    D.ctl[slot].gen = 0;
 }
 // reset() of a lazy slot whose init mode and p0 are unchanged: only the dirty records are rewritten
 // (same values as k_init_pheromone) and their flags cleared.  grid.y = slots.
@@ -1383,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0,
     const int32_t slot = slot0 + blockIdx.y;
     const int32_t n = D.dcount[slot * 2 + 1];
     const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
-    uint8_t *dirty = D.dirty + (int64_t)slot * D.dirty_stride;
+    uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
     float *ph = D.pher + (int64_t)slot * D.pher_stride;
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const int32_t id = list[q];
@@ -1397,11 +1440,33 @@ __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0,
             const float v = (inb || mode == 1) ? p0 : 0.f;
             ph[(int64_t)id * 6 + k] = adm ? v : -v;
         }
-        dirty[id] = 0;
+        stamp[id] = 0;
     }
 }
-// the field as the dense sweep would have left it: dirty records as stored, clean records at the clean value
-__global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, int32_t slot, float *out)
+// bring every deposited record current (before a solve that evaporates with a different rho: the pending
+// multiplications belong to the old one).  grid.y = slots.
+__global__ __launch_bounds__(256) void k_lazy_flush(WaAcsDev D, float rho_old)
+{
+    const int32_t slot = blockIdx.y;
+    const int32_t n = D.dcount[slot * 2 + 1];
+    const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
+    uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
+    float *ph = D.pher + (int64_t)slot * D.pher_stride;
+    const WaSlotCtl *c = &D.ctl[slot];
+    const uint32_t target = c->evap_base + (uint32_t)c->gen + 1u;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int32_t v = list[q];
+        const uint32_t old = stamp[v];
+        if (old == target) continue;
+#pragma unroll
+        for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho_old);
+        stamp[v] = target;
+    }
+}
+
+// the field as the dense sweep would have left it: deposited records with their pending evaporations applied,
+// clean records at the clean value
+__global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, WaRun R, int32_t slot, float *out)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= D.d.n * 6) return;
@@ -1409,8 +1474,9 @@ __global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, int32_t sl
     const float st0 = D.pher[(int64_t)slot * D.pher_stride + e];
     const WaSlotCtl *c = &D.ctl[slot];
     const float clean = c->clean[c->gen & 1];
-    const bool is_dirty = D.dirty[(int64_t)slot * D.dirty_stride + v] != 0;
-    out[e] = is_dirty ? fabsf(st0) : (fabsf(st0) == 0.f ? 0.f : clean);
+    const uint32_t evap_now = c->evap_base + (uint32_t)c->gen;
+    const uint32_t stv = D.stamp[(int64_t)slot * D.d.n + v];
+    out[e] = stv != 0 ? wa_catch_up(fabsf(st0), evap_now + 1u - stv, R.rho) : (fabsf(st0) == 0.f ? 0.f : clean);
 }
 
 // =====================================================================================================

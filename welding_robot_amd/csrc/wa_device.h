@@ -53,6 +53,8 @@ struct WaSlotCtl {
     // lazy evaporation (wa_acs_create_lazy): the value every never-deposited in-bounds edge holds after the
     // evaporations so far, pheromone_0 * rho * rho * ... in the reference's own fp32 rounding; slot [g & 1] like the others
     float clean[2];
+    uint32_t evap_base;     // evaporations applied to the field before generation 0 of the current solve (carried across solves)
+    uint32_t pad_;
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index

@@ -457,8 +457,7 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     e = e ? e : dalloc(&s->pher_buf[0], S * D.pher_stride);
     if (!lazy) e = e ? e : dalloc(&s->pher_buf[1], S * D.pher_stride);   // the lazy sweep is in place: one field
     if (lazy) {
-        D.dirty_stride = ((n + 3) / 4) * 4;
-        e = e ? e : dalloc(&D.dirty, S * D.dirty_stride);
+        e = e ? e : dalloc(&D.stamp, S * n);
         e = e ? e : dalloc(&D.dirty_list, S * n);
         e = e ? e : dalloc(&D.dcount, S * 2);
     }
@@ -495,7 +494,7 @@ static int acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t
     HIPC(ctx, hipMemsetAsync(s->pher_buf[0], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
     if (s->pher_buf[1]) HIPC(ctx, hipMemsetAsync(s->pher_buf[1], 0, sizeof(float) * S * D.pher_stride, ctx->stream));
     if (lazy) {
-        HIPC(ctx, hipMemsetAsync(D.dirty, 0, S * D.dirty_stride, ctx->stream));
+        HIPC(ctx, hipMemsetAsync(D.stamp, 0, sizeof(uint32_t) * S * n, ctx->stream));
         HIPC(ctx, hipMemsetAsync(D.dcount, 0, sizeof(int32_t) * S * 2, ctx->stream));
     }
     HIPC(ctx, hipMemsetAsync(D.bestmark, 0, sizeof(uint32_t) * S * n, ctx->stream));
@@ -548,7 +547,7 @@ void wa_acs_destroy(wa_acs *s)
     hipFree(s->pher_buf[0]); hipFree(s->pher_buf[1]); hipFree(D.heur); hipFree(D.mask); hipFree(D.bestmark); hipFree(D.bestpath); hipFree(D.bestpos); hipFree(D.besttabu); hipFree(D.rtab);
     hipFree(D.paths); hipFree(D.antL); hipFree(D.antLen); hipFree(D.perm); hipFree(D.depA);
     hipFree(D.sortk); hipFree(D.vbits); hipFree(D.ctl); hipFree(D.rng); hipFree(D.dbg); hipFree(D.genbase);
-    hipFree(D.dirty); hipFree(D.dirty_list); hipFree(D.dcount);
+    hipFree(D.stamp); hipFree(D.dirty_list); hipFree(D.dcount);
     if (s->graph_exec) hipGraphExecDestroy(s->graph_exec);
     if (s->graph) hipGraphDestroy(s->graph);
     hipFree(s->d_starts); hipFree(s->d_ends); hipFree(s->d_streams);
@@ -576,7 +575,7 @@ static int init_pher(wa_acs *s, int32_t slot, float p0, int mode)
         } else {
             dim3 gridf((unsigned)((s->D.d.n + 255) / 256), (unsigned)cnt);
             k_init_pheromone<<<gridf, 256, 0, s->ctx->stream>>>(s->D, slot0, p0, mode);
-            HIPC(s->ctx, hipMemsetAsync(s->D.dirty + (int64_t)slot0 * s->D.dirty_stride, 0, (size_t)cnt * s->D.dirty_stride, s->ctx->stream));
+            HIPC(s->ctx, hipMemsetAsync(s->D.stamp + (int64_t)slot0 * s->D.d.n, 0, sizeof(uint32_t) * cnt * s->D.d.n, s->ctx->stream));
         }
         k_lazy_clear<<<(cnt + 63) / 64, 64, 0, s->ctx->stream>>>(s->D, slot0, cnt, p0);
         HIPC(s->ctx, hipGetLastError());
@@ -636,6 +635,8 @@ int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
         if (start_ids[i] >= s->D.d.n || end_ids[i] >= s->D.d.n) return fail(ctx, WA_ERR_ARG, "wa_acs_begin: voxel id out of range");
     }
     WaRun &R = s->R;
+    if (s->lazy && s->begun && R.rho != p->rho)   // pending evaporations of deposited records belong to the previous rho
+        k_lazy_flush<<<dim3(64, (unsigned)s->n_slots), 256, 0, ctx->stream>>>(s->D, R.rho);
     R.alpha = p->alpha; R.beta = p->beta; R.rho = p->rho; R.pheromone_0 = p->pheromone_0;
     R.predict = p->predict; R.precision = s->grid->precision; R.fixed_colony = p->fixed_colony;
     R.rng_mode = p->rng_mode; R.seed = p->seed;
@@ -1008,7 +1009,7 @@ int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out)
     if (s->lazy) {   // the field as the dense sweep would have left it
         float *d_out = nullptr;
         if (dalloc(&d_out, (size_t)m)) return fail(ctx, WA_ERR_ALLOC, "wa_acs_read_pheromone: staging");
-        k_lazy_materialise<<<(unsigned)((m + 255) / 256), 256, 0, ctx->stream>>>(s->D, slot, d_out);
+        k_lazy_materialise<<<(unsigned)((m + 255) / 256), 256, 0, ctx->stream>>>(s->D, s->R, slot, d_out);
         hipError_t h = hipGetLastError();
         h = h ? h : hipMemcpy(out, d_out, sizeof(float) * m, hipMemcpyDeviceToHost);
         hipFree(d_out);
