@@ -378,3 +378,244 @@ __global__ __launch_bounds__(256) void k_gtsp_fast(WaGtspDev G)
         }
     }
 }
+
+// ------------------------------------------------------------------ wave-per-ant path (default for n <= 256)
+// The lanes-as-ants kernel above leaves every ant's n^2 ordered fp64 additions in one lane.  Here one WAVEFRONT
+// builds one ant's tour with the lanes spread over the CITIES (NC = 8 or 16 consecutive cities per lane), so
+// the roulette of a step is one ordered prefix chain across the wave (the sum must be taken in ascending city
+// order: whole-wave DPP, lane l continues from lane l-1's partial sum) followed by a ballot for the first city
+// whose prefix reaches the draw.  Ants of an iteration are independent => grid = (ants, instances); the
+// iteration barrier is the kernel boundary: construct -> update, two launches per iteration, the host polls the
+// stagnation stop (:263) every few iterations.
+struct WaGtspState {       // per instance, device memory
+    double pher0, bestL, last;
+    int32_t bad, it, stop, pad_;
+};
+struct WaGtspWave {
+    WaGtspDev G;
+    WaGtspState *state;    // [inst]
+    uint8_t *valid;        // [inst][n]  ant's tour visits every city exactly once
+};
+
+__device__ __forceinline__ double wa_dpp_below_f64(double x)   // lane l <- lane l-1, lane 0 <- +0.0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// ordered sum over city index: a[q] = term of city lane*NC+q (0.0 where masked: x + 0.0 == x keeps the partial sums
+// exact); returns in t[q] the running sum up to and including that city.  After round i lanes 0..i hold their final
+// values (lane l restarts from lane l-1's last partial sum each round), so `rounds` = number of lanes that own a city.
+template <int NC>
+__device__ __forceinline__ void wa_city_prefix(const double (&a)[NC], double (&t)[NC], int rounds)
+{
+    double carry = 0.0;
+#pragma unroll 2
+    for (int round = 0; round < rounds; round++) {
+        double s = carry;
+#pragma unroll
+        for (int q = 0; q < NC; q++) { s = s + a[q]; t[q] = s; }
+        carry = wa_dpp_below_f64(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gtspw_init(WaGtspWave W)
+{
+    const WaGtspDev &G = W.G;
+    const int32_t inst = blockIdx.x, tid = threadIdx.x, n = G.n;
+    const int64_t nn = (int64_t)n * n;
+    const double *dist = G.dist + inst * nn;
+    double *pher = G.pher + inst * nn, *h6 = G.h6 + inst * nn, *info = G.info + inst * nn;
+    __shared__ double s_pher0;
+    if (tid == 0) {
+        double tmp = 0;
+        for (int32_t i = 0; i < n; i++)
+            for (int32_t j = i + 1; j < n; j++) tmp += dist[(int64_t)i * n + j];  // :239-249
+        s_pher0 = (double)G.cnt / (tmp * n);
+        WaGtspState st;
+        st.pher0 = s_pher0; st.bestL = (double)0x3f3f3f3f; st.last = (double)0x3f3f3f3f;
+        st.bad = 0; st.it = 0; st.stop = 0; st.pad_ = 0;
+        W.state[inst] = st;
+        if (G.rng_mode == 0) {   // the libc draws of iteration 0 in (step, ant) order
+            int32_t rr[31];
+            for (int i = 0; i < 31; i++) rr[i] = G.rng->r[i];
+            int32_t rf = G.rng->f, rb = G.rng->b;
+            for (int32_t q = 0; q < n * (n - 1); q++) G.rbuf[q] = wa_glibc_next(rr, rf, rb);
+            for (int i = 0; i < 31; i++) G.rng->r[i] = rr[i];
+            G.rng->f = rf;
+            G.rng->b = rb;
+        }
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < nn; e += blockDim.x) {
+        const int32_t i = (int32_t)(e / n), j = (int32_t)(e % n);
+        pher[e] = s_pher0;
+        const double h = 1 / ((i == j ? 0.0 : dist[e]) + 1e-8);  // :211
+        const double hh = wa_powi(h, 6);                           // :118
+        h6[e] = hh;
+        info[e] = wa_powi(s_pher0, 1) * hh;                        // reset :114-119 for iteration 0
+    }
+}
+
+// one wavefront = ant k of instance inst, iteration `it` (construct_solution :146-159 + ACS_Tour::calc :36-44)
+template <int NC, bool STAGE>
+__global__ __launch_bounds__(64) void k_gtspw_construct(WaGtspWave W, int32_t it)
+{
+    extern __shared__ double lds_info[];   // STAGE: the whole info matrix (n*n doubles)
+    __shared__ int32_t s_tour[256];
+    const WaGtspDev &G = W.G;
+    const int32_t k = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x, n = G.n;
+    if (W.state[inst].stop) return;
+    const int64_t nn = (int64_t)n * n;
+    const double *dist = G.dist + inst * nn;
+    const double *info = G.info + inst * nn;
+    if (STAGE) {
+        for (int64_t e = lane; e < nn; e += 64) lds_info[e] = info[e];
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double *src = STAGE ? lds_info : info;
+    const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(G.seed, G.stream0 + (uint32_t)inst, (uint32_t)it), (uint32_t)k);
+    // unvisited set J[k] (:98,:111): every lane keeps the bits of its own NC cities
+    const int32_t c0 = lane * NC;
+    const int rounds = (n + NC - 1) / NC, last_lane = rounds - 1;
+    uint32_t um = 0;   // bit q: city c0+q unvisited
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+        if (c0 + q < n && c0 + q != k) um |= 1u << q;
+    int32_t r = k, left = n - 1;
+    for (int32_t step = 0; step < n; step++) {
+        int32_t next = k;  // r1[k]
+        bool picked = false;
+        if (left > 0) {    // select_next :122-144
+            const int32_t rv = G.rng_mode == 0 ? G.rbuf[step * n + k] : (int32_t)wa_ctr_draw(antkey, (uint32_t)step);
+            double rnd = (double)rv / (double)2147483647;
+            double a[NC], t[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) a[q] = ((um >> q) & 1u) ? src[(int64_t)r * n + c0 + q] : 0.0;
+            wa_city_prefix<NC>(a, t, rounds);
+            const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t[NC - 1]), last_lane),
+                                                  __builtin_amdgcn_readlane(__double2loint(t[NC - 1]), last_lane));
+            rnd *= total;
+            int myq = -1;      // first unvisited city of this lane whose running sum reaches the draw (:135-141)
+#pragma unroll
+            for (int q = NC - 1; q >= 0; q--)
+                if (((um >> q) & 1u) && t[q] >= rnd) myq = q;
+            const unsigned long long hit = __ballot(myq >= 0);
+            if (hit) {
+                const int hl = __ffsll((long long)hit) - 1;
+                next = hl * NC + __builtin_amdgcn_readlane(myq, hl);
+                picked = true;
+            }
+        }
+        if (picked) {      // J[k].erase(next) :153 -- the fallback r1[k] is not in J
+            if (lane == next / NC) um &= ~(1u << (next % NC));
+            left--;
+        }
+        if (lane == 0) {
+            s_tour[step] = next;
+            G.tours[inst * nn * 2 + (int64_t)k * n + step] = next;
+        }
+        r = next;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // tour length: the same in-order fp64 sum, closing edge excluded (:36-44)
+    double a[NC], t[NC];
+#pragma unroll
+    for (int q = 0; q < NC; q++) {
+        const int32_t e = c0 + q;
+        double term = 0.0;
+        if (e < n - 1) {
+            const int32_t ca = e == 0 ? k : s_tour[e - 1], cb = s_tour[e];
+            term = ca == cb ? 0.0 : dist[(int64_t)ca * n + cb];
+        }
+        a[q] = term;
+    }
+    wa_city_prefix<NC>(a, t, rounds);
+    if (lane == last_lane) {
+        G.antL[(int64_t)inst * n + k] = t[NC - 1];
+        W.valid[(int64_t)inst * n + k] = left == 0 ? 1 : 0;
+    }
+}
+
+// update_pheromone :161-185, the stagnation bookkeeping :269-275, and the next iteration's reset :114-119
+__global__ __launch_bounds__(256) void k_gtspw_update(WaGtspWave W, int32_t it)
+{
+    const WaGtspDev &G = W.G;
+    const int32_t inst = blockIdx.x, tid = threadIdx.x, n = G.n;
+    WaGtspState *S = &W.state[inst];
+    if (S->stop) return;
+    const int64_t nn = (int64_t)n * n;
+    double *pher = G.pher + inst * nn, *h6 = G.h6 + inst * nn, *info = G.info + inst * nn;
+    const int32_t *tours = G.tours + inst * nn * 2;
+    const double *antL = G.antL + (int64_t)inst * n;
+    int32_t *best = G.best + (int64_t)inst * n * 2;
+    const double INF = (double)0x3f3f3f3f;
+    const double alpha = 0.1;
+    __shared__ double s_L[256];
+    __shared__ int32_t s_tour[256];
+    __shared__ double s_nowL, s_bestL;
+    __shared__ int32_t s_nowk;
+    for (int32_t a = tid; a < n; a += blockDim.x) s_L[a] = antL[a];
+    __syncthreads();
+    if (tid == 0) {  // first strictly smallest tour
+        double nowL = INF;
+        int32_t nowk = -1;
+        for (int32_t a = 0; a < n; a++)
+            if (s_L[a] < nowL) { nowL = s_L[a]; nowk = a; }
+        s_nowL = nowL;
+        s_nowk = nowk;
+        s_bestL = S->bestL;
+    }
+    __syncthreads();
+    const int32_t nowk = s_nowk;
+    if (nowk >= 0)
+        for (int32_t e = tid; e < n; e += blockDim.x) s_tour[e] = tours[(int64_t)nowk * n + e];
+    for (int64_t e = tid; e < nn; e += blockDim.x) pher[e] *= (1 - alpha);  // :175-177
+    __syncthreads();
+    if (nowk >= 0 && s_nowL < s_bestL)  // best = now_best :171-174, stored as (r, s) edges
+        for (int32_t e = tid; e < n; e += blockDim.x) {
+            best[2 * e] = e == 0 ? nowk : s_tour[e - 1];
+            best[2 * e + 1] = s_tour[e];
+        }
+    // deposit :179-184 (see k_gtsp_fast: one lane per edge when the tour is a permutation, else as written)
+    const bool par_deposit = nowk >= 0 && n >= 3 && W.valid[(int64_t)inst * n + (nowk >= 0 ? nowk : 0)];
+    if (par_deposit) {
+        for (int32_t e = tid; e < n; e += blockDim.x) {
+            const int32_t a = e == 0 ? nowk : s_tour[e - 1], b = s_tour[e];
+            const double pv = pher[(int64_t)a * n + b] + 1. / (double)s_nowL;
+            pher[(int64_t)a * n + b] = pv;
+            pher[(int64_t)b * n + a] = pv;
+        }
+    } else if (nowk >= 0 && tid == 0) {
+        int32_t a = nowk;
+        for (int32_t e = 0; e < n; e++) {
+            const int32_t b = s_tour[e];
+            pher[(int64_t)a * n + b] += 1. / (double)s_nowL;
+            pher[(int64_t)b * n + a] = pher[(int64_t)a * n + b];
+            a = b;
+        }
+    }
+    __syncthreads();
+    for (int64_t e = tid; e < nn; e += blockDim.x) info[e] = wa_powi(pher[e], 1) * h6[e];  // next iteration's reset
+    if (tid == 0) {
+        WaGtspState st = *S;
+        if (nowk >= 0 && s_nowL < st.bestL) st.bestL = s_nowL;
+        if (st.last > st.bestL) { st.last = st.bestL; st.bad = 0; }
+        else st.bad++;
+        st.it = it + 1;
+        const int32_t max_it = G.max_iterations > 0 ? G.max_iterations : n * n;  // :216
+        st.stop = (st.bad > n || st.it >= max_it) ? 1 : 0;                        // :263
+        *S = st;
+        G.out_cost[inst] = st.bestL;
+        G.out_iters[inst] = st.it;
+        if (G.rng_mode == 0 && !st.stop) {   // the libc draws of the next iteration
+            int32_t rr[31];
+            for (int i = 0; i < 31; i++) rr[i] = G.rng->r[i];
+            int32_t rf = G.rng->f, rb = G.rng->b;
+            for (int32_t q = 0; q < n * (n - 1); q++) G.rbuf[q] = wa_glibc_next(rr, rf, rb);
+            for (int i = 0; i < 31; i++) G.rng->r[i] = rr[i];
+            G.rng->f = rf;
+            G.rng->b = rb;
+        }
+    }
+}

@@ -1127,7 +1127,54 @@ int wa_gtsp_solve(wa_ctx *ctx, const double *dist, int32_t n, int32_t cnt, int32
         const bool in_lds = info_bytes <= 140 * 1024;
         const unsigned threads = (unsigned)(((n + 63) / 64) * 64);
         const bool prefix = nw == 1;
-        if (n <= 256 && env_int("WA_GTSP_GENERIC", 0) == 0) {
+        // one instance (or a few): spread each ant over a wavefront; many instances already fill the GPU with the
+        // lanes-as-ants kernel (64 instances x 64 cities: 48 ms vs 82 ms), so the choice goes by the wave count
+        const bool wave_path = env_int("WA_GTSP_WAVE", (int64_t)n_instances * n <= 1024 ? 1 : 0) != 0;
+        if (n <= 256 && wave_path && env_int("WA_GTSP_GENERIC", 0) == 0) {
+            // wave-per-ant path: lanes = cities, grid = (ants, instances); construct -> update per iteration
+            WaGtspWave W;
+            W.G = G;
+            W.state = nullptr;
+            W.valid = nullptr;
+            h = dalloc(&W.state, I);
+            h = h ? h : dalloc(&W.valid, I * n);
+            // cities per lane: the n ordered additions are sequential whatever the layout, but a lane-to-lane hop
+            // (two DPP moves) costs several additions, so few lanes with many cities each win (n/NC hops per step)
+            const int nc = n <= 128 ? 8 : 16;
+            const size_t info_bytes_w = sizeof(double) * nn;
+            const bool stage = info_bytes_w <= 128 * 1024;
+            const size_t shm_w = stage ? info_bytes_w : 0;
+            const int32_t max_it = p->max_iterations > 0 ? p->max_iterations : n * n;
+            std::vector<WaGtspState> hst(I);
+#define WA_GTSPW_CONSTRUCT(NC, ST)                                                                                            \
+    do {                                                                                                                      \
+        if (!attr_set) h = hipFuncSetAttribute((const void *)k_gtspw_construct<NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_w); \
+        if (h == hipSuccess) k_gtspw_construct<NC, ST><<<dim3((unsigned)n, (unsigned)n_instances), 64, shm_w, ctx->stream>>>(W, it);           \
+    } while (0)
+            if (h == hipSuccess) {
+                k_gtspw_init<<<(unsigned)n_instances, 256, 0, ctx->stream>>>(W);
+                h = hipGetLastError();
+            }
+            bool attr_set = false;
+            for (int32_t it = 0; h == hipSuccess && it < max_it; it++) {
+                if (nc == 8) { if (stage) WA_GTSPW_CONSTRUCT(8, true); else WA_GTSPW_CONSTRUCT(8, false); }
+                else { if (stage) WA_GTSPW_CONSTRUCT(16, true); else WA_GTSPW_CONSTRUCT(16, false); }
+                attr_set = true;
+                if (h == hipSuccess) k_gtspw_update<<<(unsigned)n_instances, 256, 0, ctx->stream>>>(W, it);
+                if ((it & 7) == 7 || it == max_it - 1) {   // poll the stagnation stop (:263)
+                    h = h ? h : hipMemcpyAsync(hst.data(), W.state, sizeof(WaGtspState) * I, hipMemcpyDeviceToHost, ctx->stream);
+                    h = h ? h : hipStreamSynchronize(ctx->stream);
+                    bool all = true;
+                    for (auto &x : hst) all = all && x.stop != 0;
+                    if (all) break;
+                }
+            }
+#undef WA_GTSPW_CONSTRUCT
+            if (h == hipSuccess) h = hipGetLastError();
+            h = h ? h : hipStreamSynchronize(ctx->stream);
+            hipFree(W.state);
+            hipFree(W.valid);
+        } else if (n <= 256 && env_int("WA_GTSP_GENERIC", 0) == 0) {
             size_t shm = (in_lds ? info_bytes : 0) + (prefix ? sizeof(double) * ld * threads : 0);
 #define WA_GTSP_LAUNCH(NW, LDS, PFX)                                                                                     \
     do {                                                                                                                 \
