@@ -356,6 +356,40 @@ def test_gtsp_dev_vs_oracle(ctx):
     assert t2["L"][0] == o["L"] and t2["L"][1] == o2["L"] and np.array_equal(t2["edges"][1], o2["edges"])
 
 
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_gtsp_sizes_and_degenerate_inputs_both_kernels(ctx, wave):
+    """wave-per-ant kernels (WA_GTSP_WAVE=1) and the lanes-as-ants kernel (=0) against the oracle: sizes around the
+    lane/word boundaries, duplicate cities (ties and zero distances), an iteration cap, several instances."""
+    rs = np.random.RandomState(8)
+    os.environ["WA_GTSP_WAVE"] = wave
+    try:
+        for n in (2, 3, 9, 65, 100, 129, 200):
+            P = rs.uniform(0, 1, (n, 3))
+            if n >= 9:
+                P[3] = P[5]                                   # zero distance between two cities
+            d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1)
+            cap = 0 if n <= 100 else 12                       # the big ones: first 12 iterations
+            o = O.gtsp_solve(d, mode=O.DEV, seed=5, stream=1, max_iterations=cap, want_pher=True)
+            t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=5, stream=1, max_iterations=cap, want_pher=True)
+            assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"], n
+            assert np.array_equal(t["edges"][0], o["edges"]), n
+            assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), n
+        d3 = np.stack([d, d.T.copy(), d[::-1, ::-1].copy()])
+        t3 = api.gtsp_solve(ctx, d3, mode=api.RNG_DEV, seed=5, stream=10, max_iterations=6)
+        for q in range(3):
+            oq = O.gtsp_solve(d3[q], mode=O.DEV, seed=5, stream=10 + q, max_iterations=6)
+            assert t3["L"][q] == oq["L"] and np.array_equal(t3["edges"][q], oq["edges"])
+        # REF stream with an iteration cap: the libc state afterwards is where the oracle's is
+        rng = O.srand(77)
+        st = np.array(list(rng.r) + [rng.f, rng.b], np.int32)
+        o = O.gtsp_solve(d[:40, :40], mode=O.REF, rng=rng, max_iterations=9)
+        t = api.gtsp_solve(ctx, d[:40, :40], mode=api.RNG_REF, rand_state=st, max_iterations=9)
+        assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
+        assert [int(v) for v in t["rand_state"][:34]] == list(rng.r)
+    finally:
+        del os.environ["WA_GTSP_WAVE"]
+
+
 # ------------------------------------------------------------------ evaporation sweep (Q12 denormals)
 def test_evaporation_keeps_fp32_denormals(ctx):
     og = ogrid("cubic.stl", "0.0219", 8)
