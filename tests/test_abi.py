@@ -45,7 +45,7 @@ def test_product_never_links_the_oracle():
     for sub in ("welding_robot_amd", "include", "examples", "tools"):
         for dp, _, files in os.walk(os.path.join(ROOT, sub)):
             for f in files:
-                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".inc")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     bad = re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|libweld_oracle|oracle_lib|_ref/', txt)
                     assert not bad, (os.path.join(dp, f), bad.group(0))
