@@ -1,7 +1,7 @@
 """welding_robot_amd -- MI355X (gfx950) implementation of the ACS planning hot path of
 mhsitu/welding_robot: voxelise -> rank-based ant-colony path search -> ACS-TSP seam ordering.
 
-    csrc/            hand-written HIP kernels + the C ABI (include/weldacs.h) -> lib/libweldacs.so
+    csrc/            hand-written HIP kernels (*_kernels.hpp) + the C ABI (weldacs.hip, host_*.inc) -> lib/libweldacs.so
     include/core/    drop-in C++ headers with the reference's class names, written on the C ABI
     api.py           ctypes/numpy marshalling used by tests/ and bench.py
     build.py         in-tree hipcc build
