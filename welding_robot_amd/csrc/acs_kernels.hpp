@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
         wa_table_rows(D, R, slot, row0, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep, w0, w1);
         return;
     }
-    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..511: (bx = ab & 7, rank bit = ab >> 3)
+    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..8*ranks-1: (bx = ab & 7, rank bit = ab >> 3)
     wa_apply_body<6>(D, slot, 0, ab >> 3, ab & 7, 8, true, s_dep);
 }
 
@@ -1142,7 +1142,8 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 }
 
 // ------------------------------------------------------------------ fused post-walk launch (DEV mode)
-// One launch = ranking and deposit marking (blocks [0, 512)) + the evaporation sweep (blocks [512, 512+E)):
+// One launch = ranking and deposit marking (blocks [0, MB), MB = 8 x the most ranks that can deposit) + the
+// evaporation sweep (blocks [MB, MB+E)):
 // the sweep only touches the pheromone buffers, rank/mark only the ants' results and the rank
 // masks, so they share a launch instead of three dependent kernel boundaries.  Every mark block
 // re-derives the (L, ant) ranking in LDS (256 broadcast reads per thread); block 0 additionally
@@ -1151,15 +1152,15 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
 template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen_off)
+                                                        float *dst_base, int32_t E, int32_t gen_off, int32_t MB)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
-    // the 512 rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
+    // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
     // their latency-bound work hides under the sweep blocks that follow
-    if ((int32_t)blockIdx.x >= 512) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
+    if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
         if (!SPARSE) {
             wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
-                          (int32_t)blockIdx.x - 512, E);
+                          (int32_t)blockIdx.x - MB, E);
         } else {
             // lazy evaporation, background pass: every WA_LAZY_PERIOD-th entry of the dirty list (phase = generation)
             // is brought current in place, so no record ever has more than WA_LAZY_PERIOD multiplications pending.
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
             const float rho = R.rho;
             const int64_t first = (int64_t)(evap_now % WA_LAZY_PERIOD);
-            for (int64_t q = first + (int64_t)WA_LAZY_PERIOD * ((int64_t)((int32_t)blockIdx.x - 512) * blockDim.x + tid); q < n0;
+            for (int64_t q = first + (int64_t)WA_LAZY_PERIOD * ((int64_t)((int32_t)blockIdx.x - MB) * blockDim.x + tid); q < n0;
                  q += (int64_t)WA_LAZY_PERIOD * E * blockDim.x) {
                 const int32_t v = list[q];
                 const uint32_t old = atomicExch(&stamp[v], target);
