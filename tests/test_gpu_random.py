@@ -85,3 +85,90 @@ def test_random_problems_dense_lazy_and_26(ctx, chunk):
                         chunk, i, nb, lazy, og.nx, og.ny, og.nz, par, fixed, predict, iters, hl, e))
         finally:
             del os.environ["WA_HASH_LOG2"]
+
+
+# ---------------------------------------------------------------- the other kernels, same idea
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_meshes_voxelise_and_resolve(ctx, chunk):
+    rs = np.random.RandomState(2000 + chunk)
+    for i in range(6):
+        nt = int(rs.randint(1, 40))
+        scale = float(rs.choice([0.05, 1.0, 30.0]))
+        v = (rs.uniform(-1, 1, (nt, 3, 3)) * scale).astype(np.float32)
+        if rs.rand() < 0.5:
+            v = v[:, :1] + (rs.uniform(-0.15, 0.15, (nt, 3, 3)) * scale).astype(np.float32)   # small triangles
+        nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        tris = np.zeros((nt, 12), np.float32)
+        tris[:, :3] = nrm
+        tris[:, 3:] = v.reshape(nt, 9)
+        ext = float(np.ptp(v.reshape(-1, 3), axis=0).max())
+        p = max(ext / float(rs.randint(3, 40)), 1e-4 * scale)
+        wall = int(rs.randint(0, 6))
+        og = O.grid_from_mesh(tris, p, wall)
+        if og.n > 400000:
+            continue
+        dg = api.Grid.from_mesh(ctx, tris, p, wall)
+        assert (dg.nx, dg.ny, dg.nz) == (og.nx, og.ny, og.nz), (chunk, i)
+        assert np.array_equal(dg.occupancy(), og.free), (chunk, i, nt, p, wall)
+        pts = np.stack([rs.choice(og.cx, 12), rs.choice(og.cy, 12), rs.choice(og.cz, 12)], axis=1).astype(np.float32)
+        pts += rs.uniform(-1.5 * p, 1.5 * p, pts.shape).astype(np.float32)
+        assert np.array_equal(dg.resolve(pts), np.array([og.resolve(q) for q in pts])), (chunk, i)
+        dg.close()
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_splines(ctx, chunk):
+    rs = np.random.RandomState(3000 + chunk)
+    for i in range(10):
+        dim, deg = int(rs.randint(1, 8)), int(rs.randint(0, 8))
+        ci, cf = int(rs.randint(0, deg + 1)), int(rs.randint(0, deg + 1))
+        n = int(rs.randint(max(0, deg - ci - cf - 1), 400))
+        if deg + n + 2 + ci + cf + 1 < 2 * (deg + 1):
+            continue
+        tf = float(np.float32(rs.choice([1.0, 150.0, 6000.0, 0.37])))
+        mid = np.cumsum(rs.uniform(-0.05, 0.05, size=(n, dim)), axis=0).astype(np.float32)
+        init = rs.uniform(-1, 1, size=(ci + 1, dim)).astype(np.float32)
+        fin = rs.uniform(-1, 1, size=(cf + 1, dim)).astype(np.float32)
+        fill = int(rs.choice([0, 0x3f800000, 0x7fc00000]))
+        ob = O.Bspline(dim, deg, ci, cf, n, fill)
+        ob.set_param(init, fin, mid, tf)
+        b = api.Bspline(ctx, dim, deg, ci, cf, n, fill)
+        b.set_param(init, fin, mid, tf)
+        k, c = b.arrays()
+
+        def canon(a):   # NaN payloads are not reproduced
+            a = np.ascontiguousarray(a, np.float32)
+            u = a.view(np.uint32).ravel().copy()
+            u[np.isnan(a).ravel()] = 0x7fc00000
+            return u
+        assert np.array_equal(canon(k), canon(ob.knots)) and np.array_equal(canon(c), canon(ob.cps)), (chunk, i, dim, deg, ci, cf, n)
+        us = rs.uniform(-0.1 * tf, 1.1 * tf, size=200).astype(np.float32)
+        for der in sorted({0, min(1, deg), deg}):
+            got, ok = b.eval(us, der)
+            want, wok = ob.eval(us, der, prefill=0.0)
+            assert np.array_equal(ok, wok) and np.array_equal(canon(got), canon(want)), (chunk, i, dim, deg, ci, cf, n, der)
+        b.close()
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_random_seam_ordering(ctx, wave):
+    rs = np.random.RandomState(4000)
+    os.environ["WA_GTSP_WAVE"] = wave
+    try:
+        for i in range(16):
+            n = int(rs.randint(2, 48))
+            P = rs.uniform(0, 1, (n, 3))
+            if rs.rand() < 0.3:
+                P[rs.randint(n)] = P[rs.randint(n)]
+            d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1) if rs.rand() < 0.5 else np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
+            d = np.round(d, 3) if rs.rand() < 0.5 else d        # graph.in carries 3 decimals: many exact ties
+            cap = int(rs.choice([0, 0, 1, 7, 30]))
+            seed, stream = int(rs.randint(1 << 30)), int(rs.randint(100))
+            o = O.gtsp_solve(d, mode=O.DEV, seed=seed, stream=stream, max_iterations=cap, want_pher=True)
+            t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=seed, stream=stream, max_iterations=cap, want_pher=True)
+            assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"]), (i, n, cap)
+            assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), (i, n, cap)
+    finally:
+        del os.environ["WA_GTSP_WAVE"]
