@@ -10,6 +10,7 @@ import oracle_lib as O
 from welding_robot_amd import api
 
 pytestmark = pytest.mark.gpu
+CHUNKS = int(os.environ.get("WA_RANDOM_CHUNKS", "16"))   # 10 problems each; raise it for a soak run
 
 
 def bits(a):
@@ -65,7 +66,7 @@ def check(ctx, og, sid, eid, par, fixed, predict, iters, seed, stream, nb, lazy)
     dg.close()
 
 
-@pytest.mark.parametrize("chunk", range(16))
+@pytest.mark.parametrize("chunk", range(CHUNKS))
 def test_random_problems_dense_lazy_and_26(ctx, chunk):
     rs = np.random.RandomState(1000 + chunk)
     for i in range(10):
@@ -172,3 +173,28 @@ def test_random_seam_ordering(ctx, wave):
             assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), (i, n, cap)
     finally:
         del os.environ["WA_GTSP_WAVE"]
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_medium_problems(ctx, chunk):
+    """larger grids and colonies: replay after convergence, > 64 depositing ranks (unfused chunks), > 2048 ants"""
+    rs = np.random.RandomState(5000 + chunk)
+    for i in range(5):
+        n = int(rs.randint(14, 34))
+        og = O.synth_grid(n, seed=int(rs.randint(1 << 20)), occ_prob=float(rs.choice([0.0, 0.1, 0.2])))
+        sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, n - 1, np.float32))
+        par = dict(alpha=int(rs.choice([1, 1, 2])), beta=float(np.float32(rs.choice([0.6, 1.2]))),
+                   rho=float(np.float32(rs.choice([0.8, 0.6]))), pheromone_0=1.0)
+        fixed = int(rs.choice([30, 64, 200, 330, 2100] if i < 4 else [2100]))
+        iters = int(rs.choice([8, 20, 45])) if fixed < 2000 else 3
+        seed, stream = int(rs.randint(1 << 30)), int(rs.randint(9))
+        lazy_ok = fixed <= 2048 and int(0.2 * fixed) + 1 <= 64
+        for nb, lazy in ((6, False), (6, True), (26, False)):
+            if lazy and not lazy_ok:
+                continue
+            if nb == 26 and fixed > 400:
+                continue
+            try:
+                check(ctx, og, sid, eid, par, fixed, 3.0 * n, iters, seed, stream, nb, lazy)
+            except AssertionError as e:
+                raise AssertionError("medium chunk %d case %d nb %d lazy %s n %d par %s fixed %d iters %d: %s" % (chunk, i, nb, lazy, n, par, fixed, iters, e))
