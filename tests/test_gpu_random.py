@@ -198,3 +198,36 @@ def test_random_medium_problems(ctx, chunk):
                 check(ctx, og, sid, eid, par, fixed, 3.0 * n, iters, seed, stream, nb, lazy)
             except AssertionError as e:
                 raise AssertionError("medium chunk %d case %d nb %d lazy %s n %d par %s fixed %d iters %d: %s" % (chunk, i, nb, lazy, n, par, fixed, iters, e))
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_problems_ref_mode(ctx, chunk):
+    """WA_RNG_REF (libc stream carried on the device, libstdc++ sort order) against the oracle's REF mode, which the
+    live differential test pins to the reference itself: same draws consumed, same stream position afterwards."""
+    rs = np.random.RandomState(6000 + chunk)
+    for i in range(8):
+        og, sid, eid, par, fixed, predict, iters, seed, stream = random_case(rs)
+        iters = min(iters, 25)
+        for nb in (6, 26):
+            dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+            bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+            s = api.AcsSolver(ctx, dg, 1, max(bound, 1), neighbourhood=nb)
+            s.init_pheromone(par["pheromone_0"])
+            s.srand(seed & 0x7fffffff)
+            p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_REF, **par)
+            s.solve(p, sid, eid)
+            rng = O.srand(seed & 0x7fffffff)
+            a = O.Acs(og, pheromone_0=par["pheromone_0"], nb=nb)
+            tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.REF, rng=rng, **par)
+            t = s.trace()
+            tag = (chunk, i, nb, og.nx, og.ny, og.nz, par, fixed, predict, iters)
+            assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), tag
+            cost, path, ch = s.result()
+            assert bits(cost) == bits(a.best_L), tag
+            if np.isfinite(cost):
+                assert np.array_equal(path, a.best_path()[0]), tag
+            assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), tag
+            st = s.rand_state()
+            assert [int(v) for v in st[:31]] == list(rng.r)[:31] and int(st[34]) == rng.f and int(st[35]) == rng.b, tag   # 31 state words
+            s.close()
+            dg.close()
