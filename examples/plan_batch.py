@@ -44,11 +44,11 @@ def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=
         idx = mine[b0:b0 + slots]
         solver.solve(p, [point_ids[pairs[k][0]] for k in idx], [point_ids[pairs[k][1]] for k in idx], streams=idx)
         solver.reset_pheromone(1.0)  # reset() between problems (:481)
+        costs, ids_all = solver.results(len(idx))      # one round trip for the whole batch
         for q, k in enumerate(idx):
-            c, ids, _ = solver.result(q)
             i, j = pairs[k]
-            cost[i, j] = cost[j, i] = c
-            paths[(i, j)] = ids
+            cost[i, j] = cost[j, i] = costs[q]
+            paths[(i, j)] = ids_all[q]
     solver.close()
     return cost, paths, len(mine)
 

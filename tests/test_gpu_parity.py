@@ -337,6 +337,14 @@ def test_batch_of_problems_equals_single_runs(ctx):
         if np.isfinite(cost):
             assert np.array_equal(path, a.best_path()[0])
         assert np.array_equal(bits(sb.pheromone(k)), bits(a.pheromone()))
+    costs, ids_all = sb.results()                 # wa_acs_result_batch: one round trip, same answers
+    for k in range(len(pairs)):
+        c, path, _ = sb.result(k)
+        assert bits(costs[k]) == bits(c) and np.array_equal(ids_all[k], path)
+    lens = np.empty(len(pairs), np.int64)
+    buf = np.empty((len(pairs), 2), np.int32)
+    rc = ctx.lib.wa_acs_result_batch(sb.h, len(pairs), costs.ctypes.data, lens.ctypes.data, buf.ctypes.data, 2)
+    assert rc == 7 and lens.max() > 2             # WA_ERR_CAPACITY, lengths still reported
 
 
 def test_gtsp_dev_vs_oracle(ctx):

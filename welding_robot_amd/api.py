@@ -211,6 +211,17 @@ class AcsSolver:
             self.ctx.check(self.ctx.lib.wa_acs_result(self.h, slot, C.byref(cost), C.byref(n), _ptr(ids), _ptr(ch), n.value))
         return np.float32(cost.value), ids, ch
 
+    def results(self, n_slots=None):
+        """(costs, [path ids per slot]) of slots 0..n_slots-1 in one round trip"""
+        n = self.n_slots if n_slots is None else n_slots
+        costs, lens = np.empty(n, np.float32), np.empty(n, np.int64)
+        self.ctx.check(self.ctx.lib.wa_acs_result_batch(self.h, n, _ptr(costs), _ptr(lens), None, 0))
+        stride = int(lens.max()) if n else 0
+        buf = np.empty((n, max(stride, 1)), np.int32)
+        if stride:
+            self.ctx.check(self.ctx.lib.wa_acs_result_batch(self.h, n, _ptr(costs), _ptr(lens), _ptr(buf), stride))
+        return costs, [buf[q, :lens[q]].copy() for q in range(n)]
+
     def trace(self, slot=0):
         g = C.c_int32()
         self.ctx.check(self.ctx.lib.wa_acs_trace(self.h, slot, C.byref(g), None, None, None, None, None))
