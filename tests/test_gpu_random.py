@@ -11,6 +11,7 @@ from welding_robot_amd import api
 
 pytestmark = pytest.mark.gpu
 CHUNKS = int(os.environ.get("WA_RANDOM_CHUNKS", "16"))   # 10 problems each; raise it for a soak run
+CHUNKS4 = max(4, CHUNKS // 4)
 
 
 def bits(a):
@@ -89,7 +90,7 @@ def test_random_problems_dense_lazy_and_26(ctx, chunk):
 
 
 # ---------------------------------------------------------------- the other kernels, same idea
-@pytest.mark.parametrize("chunk", range(4))
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
 def test_random_meshes_voxelise_and_resolve(ctx, chunk):
     rs = np.random.RandomState(2000 + chunk)
     for i in range(6):
@@ -119,7 +120,7 @@ def test_random_meshes_voxelise_and_resolve(ctx, chunk):
         dg.close()
 
 
-@pytest.mark.parametrize("chunk", range(4))
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
 def test_random_splines(ctx, chunk):
     rs = np.random.RandomState(3000 + chunk)
     for i in range(10):
@@ -175,7 +176,7 @@ def test_random_seam_ordering(ctx, wave):
         del os.environ["WA_GTSP_WAVE"]
 
 
-@pytest.mark.parametrize("chunk", range(3))
+@pytest.mark.parametrize("chunk", range(max(3, CHUNKS // 8)))
 def test_random_medium_problems(ctx, chunk):
     """larger grids and colonies: replay after convergence, > 64 depositing ranks (unfused chunks), > 2048 ants"""
     rs = np.random.RandomState(5000 + chunk)
@@ -200,7 +201,7 @@ def test_random_medium_problems(ctx, chunk):
                 raise AssertionError("medium chunk %d case %d nb %d lazy %s n %d par %s fixed %d iters %d: %s" % (chunk, i, nb, lazy, n, par, fixed, iters, e))
 
 
-@pytest.mark.parametrize("chunk", range(4))
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
 def test_random_problems_ref_mode(ctx, chunk):
     """WA_RNG_REF (libc stream carried on the device, libstdc++ sort order) against the oracle's REF mode, which the
     live differential test pins to the reference itself: same draws consumed, same stream position afterwards."""
