@@ -599,6 +599,13 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
         const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
+#ifdef WA_STAMPS
+        if (lane == 0 && D.dbg) {   // diagnostic: how far do ants follow the best path?  [10] += nodes replayed, [11] += ants,
+            atomicAdd(&D.dbg[10], (unsigned long long)node);          // [12] += ants that arrived on the replay track
+            atomicAdd(&D.dbg[11], 1ULL);
+            if (what == 2) atomicAdd(&D.dbg[12], 1ULL);
+        }
+#endif
         st.len = node + 1;
         for (int32_t q = lane; q < st.len; q += 64) path[q] = bpath[q];  // the walked prefix IS the best path's
         if (what != 3) {  // finished on the replay track
