@@ -163,6 +163,9 @@ int wa_acs_trace(wa_acs *s, int32_t slot, int32_t *generations_done, float *best
  * slot into dst_device[slot*count + g] -- feeds the RCCL MIN all-reduce of the global best */
 int wa_acs_export_trace(wa_acs *s, void *dst_device, int32_t gen0, int32_t count);
 int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out /* nvox*6 */);
+/* the agents[] of the generation walked last (ACSRank_3D.hpp:251-261): per ant L (+inf = dead end, :88-91) and node
+ * count (Agent::getPath()->size()); *colony = ants of that generation, of which min(colony, cap) are written. */
+int wa_acs_read_ants(wa_acs *s, int32_t slot, int32_t *colony, float *L, int32_t *len, int32_t cap);
 int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, float *Q);
 
 /* kernel timing with HIP events on the context stream.  Enable before wa_acs_run; afterwards

@@ -379,6 +379,9 @@ struct wo_acs {
     wo_ant best;          /* persists across solves (Q9) */
     int32_t last_colony;
     float last_lambda, last_Q;
+    int32_t *last_len;    /* per-ant node count / L of the last generation walked (agents[] of :251) */
+    float *last_L;
+    int32_t last_cap;
 };
 
 static void ant_push(wo_ant *a, int32_t id, int8_t ch)
@@ -447,7 +450,7 @@ void wo_acs_destroy(wo_acs *s)
 {
     if (!s) return;
     free(s->cx); free(s->cy); free(s->cz); free(s->free_); free(s->pher); free(s->visit);
-    free(s->bestmark); free(s->best.ids); free(s->best.choice); free(s);
+    free(s->bestmark); free(s->best.ids); free(s->best.choice); free(s->last_len); free(s->last_L); free(s);
 }
 
 void wo_acs_reset(wo_acs *s, float pheromone_0)
@@ -630,6 +633,12 @@ int32_t wo_acs_solve(wo_acs *s, const wo_acs_params *p, int64_t start_id, int64_
         if (trace_finite) trace_finite[g] = finite;
         if (trace_steps) trace_steps[g] = steps;
         s->last_colony = colony; s->last_lambda = lambda; s->last_Q = Q;
+        if (colony > s->last_cap) {
+            s->last_len = (int32_t *)realloc(s->last_len, sizeof(int32_t) * (size_t)colony);
+            s->last_L = (float *)realloc(s->last_L, sizeof(float) * (size_t)colony);
+            s->last_cap = colony;
+        }
+        for (int32_t a = 0; a < colony; a++) { s->last_len[a] = (int32_t)ants[a].len; s->last_L[a] = ants[a].L; }
     }
     for (int32_t a = 0; a < ants_cap; a++) { free(ants[a].ids); free(ants[a].choice); }
     free(ants); free(keys); free(perm);
@@ -648,6 +657,11 @@ const float *wo_acs_pheromone(const wo_acs *s) { return s->pher; }
 void wo_acs_last_params(const wo_acs *s, int32_t *colony, float *lambda, float *Q)
 {
     *colony = s->last_colony; *lambda = s->last_lambda; *Q = s->last_Q;
+}
+int32_t wo_acs_last_ants(const wo_acs *s, int32_t *lens, float *L)
+{
+    for (int32_t a = 0; a < s->last_colony; a++) { if (lens) lens[a] = s->last_len[a]; if (L) L[a] = s->last_L[a]; }
+    return s->last_colony;
 }
 
 /* ================================================================== ACS_GTSP ======= */

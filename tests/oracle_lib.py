@@ -90,6 +90,8 @@ def lib():
         L.wo_acs_pheromone.restype = C.POINTER(C.c_float)
         L.wo_acs_pheromone.argtypes = [C.c_void_p]
         L.wo_acs_last_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wo_acs_last_ants.restype = C.c_int32
+        L.wo_acs_last_ants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.wo_acs_heuristic.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
         L.wo_gtsp_solve.restype = C.c_int32
         L.wo_gtsp_solve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GtspParams), C.c_void_p,
@@ -260,6 +262,12 @@ class Acs:
         c, l, q = C.c_int32(), C.c_float(), C.c_float()
         lib().wo_acs_last_params(self.h, C.byref(c), C.byref(l), C.byref(q))
         return c.value, np.float32(l.value), np.float32(q.value)
+
+    def last_ants(self):
+        n = lib().wo_acs_last_ants(self.h, None, None)
+        lens, L = np.empty(n, np.int32), np.empty(n, np.float32)
+        lib().wo_acs_last_ants(self.h, lens.ctypes.data, L.ctypes.data)
+        return lens, L
 
     def heuristic(self, end_id, beta=0.6):
         out = np.empty(self.grid.n * self.nb, np.float32)

@@ -240,6 +240,14 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_read_pheromone(self.h, slot, _ptr(out)))
         return out
 
+    def ants(self, slot=0):
+        """(L, node count) per ant of the generation walked last"""
+        c = C.c_int32()
+        self.ctx.check(self.ctx.lib.wa_acs_read_ants(self.h, slot, C.byref(c), None, None, 0))
+        Ls, lens = np.empty(c.value, np.float32), np.empty(c.value, np.int32)
+        self.ctx.check(self.ctx.lib.wa_acs_read_ants(self.h, slot, C.byref(c), _ptr(Ls), _ptr(lens), c.value))
+        return Ls, lens
+
     def last_params(self, slot=0):
         c, l, q = C.c_int32(), C.c_float(), C.c_float()
         self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))
