@@ -54,6 +54,8 @@ struct WaAcsDev {
     uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
+    float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
+    int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t *genbase;              // device generation counter: kernels of the fused DEV loop run generation *genbase + gen_off,
                                    // which lets a captured hipGraph of G generations be replayed (the graph's last kernel adds G)
 };
@@ -150,6 +152,20 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 __global__ void k_set_genbase(WaAcsDev D, int32_t v) { *D.genbase = v; }
+
+// L as a function of the step count: Agent::addNextNode adds `distance` (== precision for face moves, :378) once per
+// step (:78), sequentially in fp32 -- not i * precision.  One wavefront runs the chain, lane l keeps entry 64c + l.
+__global__ __launch_bounds__(64) void k_ltab(float *ltab, int32_t count, float precision)
+{
+    float L = 0.f, mine = 0.f;
+    for (int32_t base = 0; base < count; base += 64) {
+        for (int q = 0; q < 64; q++) {
+            if ((int)threadIdx.x == q) mine = L;
+            L += precision;
+        }
+        if (base + (int32_t)threadIdx.x < count) ltab[base + threadIdx.x] = mine;
+    }
+}
 
 #define WA_LAZY_PERIOD 16
 // stored value -> value after `lag` more evaporations (:270, one rounding per multiplication like the sweep)
@@ -434,6 +450,228 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
 }
 
+// ------------------------------------------------------------------ the hand-scheduled walk loop
+// DEV mode, alpha == 1, dense field.  Same arithmetic, same operands, same order as wa_walk_fast (the tests hold the
+// two against each other and against the oracle); what changes is what a LONE wavefront pays for: it issues one
+// instruction per ~4 cycles whatever the type, so a step costs (instructions x 4 cycles) + whatever memory latency is
+// left exposed.  The compiler's loop is ~85 instructions and waits for vmcnt(0) at its back edge; this one is ~60 and
+// keeps three generations of loads in flight with exact vmcnt counts:
+//   * records of the six neighbours (needed NEXT step) are requested first, then the records TWO hops away are touched
+//     with two 16-byte loads nobody waits for: by the time they are requested for real they sit in L2 (vector memory
+//     returns in order, so the younger touch loads never hold back the older record loads);
+//   * lanes are laid out so that the roulette's first hit (scanning edge 5 down to 0) is the LOWEST set bit: role k
+//     sits at position 5-k of its 8-lane block, `total` lands in position 0, one s_ff1 picks; block b holds the
+//     record of neighbour 5-b, so the next active block is the picked lane's position;
+//   * no address clamp (guard bands around the fields), no per-step L (table lookup at the end), the path word and the
+//     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
+//     dummy slot), limits are checked per 64-step block instead of per step.
+// Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
+#define WA_WALK_LDS_EXTRA 2048   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants
+#define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
+#define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
+// one step: CP/CH = records of `cur` (arrived or arriving), NP/NH = where the neighbours' records go, X = label suffix
+#define WA_ASM_STEP(CP, CH, NP, NH, X)                                                                            \
+    "s_mul_i32 s40, %[cur], 24\n"                                                                                 \
+    "v_add_u32 v82, s40, v65\n"                                                                                   \
+    "global_load_dword " NP ", v82, %[pher]\n"                                                                    \
+    "global_load_dword " NH ", v82, %[heur]\n"                                                                    \
+    "v_add_u32 v83, s40, v66\n"                                                                                   \
+    "global_load_dwordx4 v[86:89], v83, %[pher]\n"                                                                \
+    "global_load_dwordx4 v[90:93], v83, %[heur]\n"                                                                \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
+    "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
+    "Lwa_res_" X "%=:\n"                                                                                          \
+    "s_waitcnt vmcnt(6)\n"                                        /* records of cur; 2 touch + 4 new loads stay in flight */ \
+    "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
+    "v_mul_f32 v78, |" CP "|, " CH "\n"                           /* info (:154), alpha == 1 */                   \
+    "s_and_b64 s[50:51], s[50:51], vcc\n"                         /* ... and not visited (:145) */                \
+    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active group */                   \
+    "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
+    "v_add_f32 v79, 0, v78\n"                                                                                     \
+    "v_readlane_b32 s42, %[ub], m0\n"                             /* this step's uniform draw (:169) */           \
+    "v_add_u32 v85, %[cur], v69\n"                                /* candidate path words: (cur + d_k) | k << 29 */ \
+    "v_add_f32_dpp v80, v79, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "s_nop 0\n"                                                                                                   \
+    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "s_nop 0\n"                                                                                                   \
+    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "s_nop 0\n"                                                                                                   \
+    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "s_nop 0\n"                                                                                                   \
+    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "v_mul_f32 v81, s42, v79\n"                                   /* rnd = u * total (:170), valid in position 0 */ \
+    "s_nop 0\n"                                                                                                   \
+    "v_readlane_b32 s43, v81, %[g8]\n"                                                                            \
+    "s_nop 1\n"                                                                                                   \
+    "v_cmp_le_f32 vcc, s43, v80\n"                                /* prob_sum >= rnd (:178) */                    \
+    "s_and_b64 s[56:57], vcc, s[52:53]\n"                                                                         \
+    "s_cbranch_scc0 Lwa_dead%=\n"                                 /* no candidate (:162) or fall-through (:191) */ \
+    "s_ff1_i32_b64 s45, s[56:57]\n"                               /* first hit scanning edge 5 -> 0 */            \
+    "v_cmp_eq_u32 vcc, s45, v64\n"                                                                                \
+    "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
+    "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
+    "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
+    "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
+    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
+    "v_add_u32 v77, s41, v67\n"                                                                                   \
+    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
+    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
+    "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
+    "v_add_u32 v76, %[cur], v68\n"                                                                                \
+    "s_lshl_b32 %[g8], s45, 3\n"                                 /* next active block = position of the pick (low 6 bits count) */ \
+    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
+    "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
+    "s_add_i32 m0, m0, 1\n"                                                                                       \
+    "s_and_b32 s46, m0, 63\n"                                                                                     \
+    "s_cbranch_scc0 Lwa_bnd_" X "%=\n"                            /* block of 64 path words complete */           \
+    "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
+    "s_cbranch_scc1 Lwa_arr_" X "%=\n"
+// rare: some lane's probe hit another key: advance those lanes along their chains
+#define WA_ASM_COLL(X)                                                                                            \
+    "Lwa_coll_" X "%=:\n"                                                                                         \
+    "s_mov_b64 s[58:59], exec\n"                                                                                  \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "v_add_u32 v77, 4, v77\n"                                                                                     \
+    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
+    "ds_read_b32 v75, v77\n"                                                                                      \
+    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "v_cmp_ne_u32 vcc, v75, v76\n"                                                                                \
+    "v_cmp_ne_u32 s[48:49], -1, v75\n"                                                                            \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
+    "s_branch Lwa_res_" X "%=\n"
+
+__device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
+                                                 int32_t *__restrict__ path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
+                                                 int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
+                                                 int32_t guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
+                                                 int32_t *flags_out, const int32_t *prefix_words)
+{
+    const int lane = threadIdx.x;
+    const int j = lane >> 3, pos = lane & 7;
+    const int k2 = pos < 6 ? 5 - pos : 0;   // edge this lane evaluates; positions 6,7 of a group are padding (never admissible)
+    // lane block b = lane >> 3 fetches the record of neighbour 5 - b: the block that becomes active after a move is
+    // then the POSITION of the picked lane (edge k sits at position 5 - k), one s_lshl away from the pick
+    const int32_t dk = wa_delta(k2, nx, nxy), dj = wa_delta(j < 6 ? 5 - j : 5, nx, nxy);
+    const int32_t limit = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
+    const int32_t table = 1 << hash_log2;
+    // field bases moved back by the guard band: every offset the loop forms is then non-negative
+    const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
+    const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
+    {   // lane constants (columns of 64 dwords behind the dummy slots)
+        int32_t *lc = tab + table + 64;
+        lc[0 * 64 + lane] = lane;
+        lc[1 * 64 + lane] = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
+        lc[2 * 64 + lane] = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
+        lc[3 * 64 + lane] = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
+        lc[4 * 64 + lane] = dk;
+        lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
+        lc[6 * 64 + lane] = (table + lane) * 4;                                      // this lane's dummy slot
+    }
+    const int32_t lcaddr = (table + 64 + lane) * 4;
+    int32_t cur = st.cur, len = st.len, g8 = 0;
+    int32_t pbuf = st.cur;
+    if (prefix_words) pbuf = lane < (st.len & 63) ? prefix_words[(st.len & ~63) + lane] : 0;
+    float ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
+    float p = -0.f, h = 0.f;
+    if (j == 0 && pos < 6) {
+        const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
+        p = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pher) + boff);
+        h = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(heur) + boff);
+    }
+    const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
+    int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on
+    for (;;) {
+        // the loop checks its limits once per 64-step block: only enter a block that fits entirely
+        if ((len | 63) + 1 > limit) { exit_code = 3; break; }
+        int32_t code;
+        asm volatile(
+            "ds_read_b32 v64, %[lc]\n"
+            "ds_read_b32 v65, %[lc] offset:256\n"
+            "ds_read_b32 v66, %[lc] offset:512\n"
+            "ds_read_b32 v67, %[lc] offset:768\n"
+            "ds_read_b32 v68, %[lc] offset:1024\n"
+            "ds_read_b32 v69, %[lc] offset:1280\n"
+            "ds_read_b32 v70, %[lc] offset:1536\n"
+            "v_mov_b32 v71, %[pio]\n"
+            "v_mov_b32 v72, %[hio]\n"
+            "s_lshl_b64 s[54:55], 63, %[g8]\n"
+            "s_mov_b32 m0, %[len]\n"                      // the node count lives in m0: lane select of the draw and of the path word
+            "s_mul_i32 s41, %[cur], 0x9e3779b1\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_add_u32 v77, s41, v67\n"
+            "v_lshrrev_b32 v77, %[hs], v77\n"
+            "v_lshlrev_b32 v77, 2, v77\n"
+            "ds_read_b32 v75, v77\n"
+            "v_add_u32 v76, %[cur], v68\n"
+            "Lwa_top%=:\n"
+            WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
+            WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
+            "s_branch Lwa_top%=\n"
+            WA_ASM_COLL("a")
+            WA_ASM_COLL("b")
+            "Lwa_dead%=:\n"
+            "s_mov_b32 %[code], 1\n"
+            "s_branch Lwa_out%=\n"
+            "Lwa_bnd_a%=:\n"
+            "s_mov_b32 %[code], 0\n"
+            "s_branch Lwa_out_a%=\n"
+            "Lwa_arr_a%=:\n"
+            "s_mov_b32 %[code], 2\n"
+            "Lwa_out_a%=:\n"
+            "s_waitcnt vmcnt(0)\n"
+            "v_mov_b32 %[pio], v73\n"
+            "v_mov_b32 %[hio], v74\n"
+            "s_branch Lwa_out%=\n"
+            "Lwa_bnd_b%=:\n"
+            "s_mov_b32 %[code], 0\n"
+            "s_branch Lwa_out_b%=\n"
+            "Lwa_arr_b%=:\n"
+            "s_mov_b32 %[code], 2\n"
+            "Lwa_out_b%=:\n"
+            "s_waitcnt vmcnt(0)\n"
+            "v_mov_b32 %[pio], v71\n"
+            "v_mov_b32 %[hio], v72\n"
+            "Lwa_out%=:\n"
+            "s_mov_b32 %[len], m0\n"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf)
+            : [ub] "v"(ublock), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end)
+            : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
+              "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "s40", "s41", "s42", "s43",
+              "s44", "s45", "s46", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc",
+              "m0", "memory");
+        if (code == 0) {   // a block of 64 path words is complete: one coalesced store, next block of draws
+            path[(len - 64) + lane] = pbuf;
+            if (cur == end) { exit_code = 2; break; }
+            ublock = (float)wa_ctr_draw(antkey, (uint32_t)(len + lane - 1)) / 2147483648.0f;
+            continue;
+        }
+        exit_code = code;
+        break;
+    }
+    float L = exit_code == 1 ? INFINITY : ltab[len - 1];   // :78, one add of `precision` per step taken
+    st.done = exit_code != 3;
+    if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
+        if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+        L = INFINITY;
+        st.done = true;
+    }
+    if (len & 63) {  // partial last block (entries [len & ~63, len))
+        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
+    }
+    st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
+}
+
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
 template <int MODE, bool SPARSE>
 __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, const float *pher, const float *heur,
@@ -584,7 +822,7 @@ template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
-                                            int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now)
+                                            int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
@@ -646,7 +884,14 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     }
     __builtin_amdgcn_wave_barrier();
     const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
-    if (st.len < fast_limit)
+    bool use_asm = false;
+#ifndef WA_STAMPS
+    use_asm = MODE == 1 && ALPHA1 && !SPARSE && (walk_flags & 1);
+#endif
+    if (st.len < fast_limit && use_asm)
+        wa_walk_fast_asm(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at, D.guard_bytes, D.ltab, st,
+                         flags_out, prefix_words);
+    else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
     else if (st.len >= (int32_t)D.path_cap) {  // cannot happen after a replay (the best path fits), kept for symmetry
@@ -786,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
 template <bool ALPHA1, bool SPARSE>
-__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen_off)
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen_off, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
@@ -799,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const float bestL = c->bestL;
     const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
     wa_walk_one<1, ALPHA1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
-                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen);
+                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -818,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u);
+        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;

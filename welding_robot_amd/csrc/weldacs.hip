@@ -56,7 +56,9 @@ struct wa_acs {
     int64_t path_cap;
     WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
+    float *pher_alloc[2], *heur_alloc;   // the allocations behind pher_buf[] / D.heur (fields + guard bands)
     int cur_buf;
+    bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     WaRun R;
     bool begun, overlap_walk, overlap_rank, fuse, inplace, fuse_table;
     bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
