@@ -466,35 +466,61 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
 //     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
 //     dummy slot), limits are checked per 64-step block instead of per step.
 // Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
-#define WA_WALK_LDS_EXTRA 2048   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants
+#define WA_WALK_LDS_EXTRA 4096   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants (+ 6 x 64 diagnostic sums)
 #define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
 #define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
-// one step: CP/CH = records of `cur` (arrived or arriving), NP/NH = where the neighbours' records go, X = label suffix
+// experiment switches (timing studies only; the product build defines none of them)
+#if defined(WA_ASM_NOWARM)
+#define WA_ASM_WARM_ADDR ""
+#define WA_ASM_WARM0 "s_nop 0\n"
+#define WA_ASM_WARM1 "s_nop 0\n"
+#define WA_ASM_VMWAIT "s_waitcnt vmcnt(2)\n"
+#else
+#define WA_ASM_WARM_ADDR "v_add_u32 v83, s40, v66\n"
+#define WA_ASM_WARM0 "global_load_dwordx4 v[86:89], v83, %[pher]\n"
+#define WA_ASM_WARM1 "global_load_dwordx4 v[90:93], v83, %[heur]\n"
+#define WA_ASM_VMWAIT "s_waitcnt vmcnt(4)\n"
+#endif
+// -DWA_ASM_STAMPS (diagnostic builds, tools/walk_stamps_asm.py): s_memtime at six points of the step, differences summed in
+// s72..s77 (s70 = previous stamp); each stamp drains LDS and costs ~40 cycles: read the shares, not the totals
+#if defined(WA_ASM_STAMPS)
+#define WA_ASM_STAMP(i) "s_memtime s[60:61]\n" "s_waitcnt lgkmcnt(0)\n" "s_sub_u32 s62, s60, s70\n" "s_add_u32 s" #i ", s" #i ", s62\n" "s_mov_b32 s70, s60\n"
+#else
+#define WA_ASM_STAMP(i) ""
+#endif
+// One step.  CP/CH = records of `cur` (arrived or arriving), NP/NH = where the neighbours' records go, X = label suffix.
+// Schedule rules (measured with tools/ubench/issue_rates.hip, one wave alone on its SIMD): every instruction costs
+// ~4.3 cycles; an SALU instruction reading an SGPR/VCC that a VALU instruction wrote stalls ~16 cycles unless four
+// other instructions sit between them; a conditional branch costs ~13 cycles not taken, ~23 taken.  Hence: compares
+// early, their scalar consumers late, and ONE rare-event branch per step -- a completed 64-word block and the arrival
+// zero the active-lane mask, so the NEXT step finds no candidate and leaves through the same exit as a dead end.
 #define WA_ASM_STEP(CP, CH, NP, NH, X)                                                                            \
     "s_mul_i32 s40, %[cur], 24\n"                                                                                 \
     "v_add_u32 v82, s40, v65\n"                                                                                   \
-    "global_load_dword " NP ", v82, %[pher]\n"                                                                    \
+    "global_load_dword " NP ", v82, %[pher]\n"                    /* records of the six neighbours: needed next step */ \
     "global_load_dword " NH ", v82, %[heur]\n"                                                                    \
-    "v_add_u32 v83, s40, v66\n"                                                                                   \
-    "global_load_dwordx4 v[86:89], v83, %[pher]\n"                                                                \
-    "global_load_dwordx4 v[90:93], v83, %[heur]\n"                                                                \
+    WA_ASM_WARM_ADDR                                                                                              \
+    "Lwa_redo_" X "%=:\n"                                                                                         \
+    WA_ASM_STAMP(72)                                                                                              \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    WA_ASM_STAMP(73)                                                                                              \
     "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
     "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
-    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
-    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
-    "Lwa_res_" X "%=:\n"                                                                                          \
-    "s_waitcnt vmcnt(6)\n"                                        /* records of cur; 2 touch + 4 new loads stay in flight */ \
+    WA_ASM_VMWAIT                                                 /* records of cur; the touch loads + the 2 new ones stay in flight */ \
+    WA_ASM_STAMP(74)                                                                                              \
     "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
     "v_mul_f32 v78, |" CP "|, " CH "\n"                           /* info (:154), alpha == 1 */                   \
+    WA_ASM_WARM0                                                  /* records two hops away: touched, never waited for */ \
+    WA_ASM_WARM1                                                                                                  \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
     "s_and_b64 s[50:51], s[50:51], vcc\n"                         /* ... and not visited (:145) */                \
-    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active group */                   \
+    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active block */                   \
     "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
-    "v_add_f32 v79, 0, v78\n"                                                                                     \
     "v_readlane_b32 s42, %[ub], m0\n"                             /* this step's uniform draw (:169) */           \
     "v_add_u32 v85, %[cur], v69\n"                                /* candidate path words: (cur + d_k) | k << 29 */ \
-    "v_add_f32_dpp v80, v79, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "v_add_f32_dpp v80, v78, v78" WA_ASM_DPP_C                                                                    \
+    "v_add_f32_dpp v79, v78, v78" WA_ASM_DPP_T                                                                    \
     "s_nop 0\n"                                                                                                   \
     "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
     "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
@@ -507,18 +533,22 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     "s_nop 0\n"                                                                                                   \
     "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
     "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    WA_ASM_STAMP(75)                                                                                              \
     "v_mul_f32 v81, s42, v79\n"                                   /* rnd = u * total (:170), valid in position 0 */ \
     "s_nop 0\n"                                                                                                   \
     "v_readlane_b32 s43, v81, %[g8]\n"                                                                            \
     "s_nop 1\n"                                                                                                   \
     "v_cmp_le_f32 vcc, s43, v80\n"                                /* prob_sum >= rnd (:178) */                    \
     "s_and_b64 s[56:57], vcc, s[52:53]\n"                                                                         \
-    "s_cbranch_scc0 Lwa_dead%=\n"                                 /* no candidate (:162) or fall-through (:191) */ \
+    "s_cbranch_scc0 Lwa_rare_" X "%=\n"                           /* no candidate (:162), fall-through (:191), or a pending event */ \
+    WA_ASM_STAMP(76)                                                                                              \
     "s_ff1_i32_b64 s45, s[56:57]\n"                               /* first hit scanning edge 5 -> 0 */            \
     "v_cmp_eq_u32 vcc, s45, v64\n"                                                                                \
     "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
     "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
     "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
+    "s_lshl_b32 %[g8], s45, 3\n"                                  /* next active block = position of the pick (low 6 bits count) */ \
+    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
     "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
     "v_add_u32 v77, s41, v67\n"                                                                                   \
@@ -526,15 +556,14 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
     "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
     "v_add_u32 v76, %[cur], v68\n"                                                                                \
-    "s_lshl_b32 %[g8], s45, 3\n"                                 /* next active block = position of the pick (low 6 bits count) */ \
-    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
     "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
     "s_add_i32 m0, m0, 1\n"                                                                                       \
     "s_and_b32 s46, m0, 63\n"                                                                                     \
-    "s_cbranch_scc0 Lwa_bnd_" X "%=\n"                            /* block of 64 path words complete */           \
-    "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
-    "s_cbranch_scc1 Lwa_arr_" X "%=\n"
-// rare: some lane's probe hit another key: advance those lanes along their chains
+    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* block of 64 path words complete: event */    \
+    "s_cmp_lg_u32 %[cur], %[end]\n"                                                                               \
+    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* arrived (:182): event */                     \
+    WA_ASM_STAMP(77)
+// some lane's probe hit another key: advance those lanes along their chains, then evaluate the step again
 #define WA_ASM_COLL(X)                                                                                            \
     "Lwa_coll_" X "%=:\n"                                                                                         \
     "s_mov_b64 s[58:59], exec\n"                                                                                  \
@@ -543,18 +572,22 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     "v_and_b32 v77, %[hm4], v77\n"                                                                                \
     "ds_read_b32 v75, v77\n"                                                                                      \
     "s_mov_b64 exec, s[58:59]\n"                                                                                  \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    "v_cmp_ne_u32 vcc, v75, v76\n"                                                                                \
-    "v_cmp_ne_u32 s[48:49], -1, v75\n"                                                                            \
-    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
-    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
-    "s_branch Lwa_res_" X "%=\n"
+    "s_branch Lwa_redo_" X "%=\n"
+// no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
+// CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
+#define WA_ASM_RARE(CP, CH, X)                                                                                    \
+    "Lwa_rare_" X "%=:\n"                                                                                         \
+    "v_mov_b32 %[pio], " CP "\n"                                                                                  \
+    "v_mov_b32 %[hio], " CH "\n"                                                                                  \
+    "s_cmp_eq_u64 s[54:55], 0\n"                                                                                  \
+    "s_cbranch_scc0 Lwa_dead%=\n"                                                                                 \
+    "s_branch Lwa_event%=\n"
 
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  int32_t *__restrict__ path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
                                                  int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
                                                  int32_t guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
-                                                 int32_t *flags_out, const int32_t *prefix_words)
+                                                 int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg)
 {
     const int lane = threadIdx.x;
     const int j = lane >> 3, pos = lane & 7;
@@ -613,43 +646,49 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             "v_lshlrev_b32 v77, 2, v77\n"
             "ds_read_b32 v75, v77\n"
             "v_add_u32 v76, %[cur], v68\n"
+#if defined(WA_ASM_STAMPS)
+            "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n"
+            "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
+#endif
             "Lwa_top%=:\n"
             WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
             WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
+            WA_ASM_STEP("v71", "v72", "v73", "v74", "c")
+            WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
             "s_branch Lwa_top%=\n"
-            WA_ASM_COLL("a")
-            WA_ASM_COLL("b")
+            WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
+            WA_ASM_RARE("v71", "v72", "a") WA_ASM_RARE("v73", "v74", "b") WA_ASM_RARE("v71", "v72", "c") WA_ASM_RARE("v73", "v74", "d")
             "Lwa_dead%=:\n"
             "s_mov_b32 %[code], 1\n"
             "s_branch Lwa_out%=\n"
-            "Lwa_bnd_a%=:\n"
-            "s_mov_b32 %[code], 0\n"
-            "s_branch Lwa_out_a%=\n"
-            "Lwa_arr_a%=:\n"
+            "Lwa_event%=:\n"                               // a complete block takes precedence: the caller flushes it, then tests arrival itself
             "s_mov_b32 %[code], 2\n"
-            "Lwa_out_a%=:\n"
-            "s_waitcnt vmcnt(0)\n"
-            "v_mov_b32 %[pio], v73\n"
-            "v_mov_b32 %[hio], v74\n"
-            "s_branch Lwa_out%=\n"
-            "Lwa_bnd_b%=:\n"
+            "s_and_b32 s46, m0, 63\n"
+            "s_cbranch_scc1 Lwa_out%=\n"
             "s_mov_b32 %[code], 0\n"
-            "s_branch Lwa_out_b%=\n"
-            "Lwa_arr_b%=:\n"
-            "s_mov_b32 %[code], 2\n"
-            "Lwa_out_b%=:\n"
-            "s_waitcnt vmcnt(0)\n"
-            "v_mov_b32 %[pio], v71\n"
-            "v_mov_b32 %[hio], v72\n"
             "Lwa_out%=:\n"
             "s_mov_b32 %[len], m0\n"
+#if defined(WA_ASM_STAMPS)
+            "v_mov_b32 v94, s72\n ds_write_b32 %[lc], v94 offset:1792\n v_mov_b32 v94, s73\n ds_write_b32 %[lc], v94 offset:2048\n"
+            "v_mov_b32 v94, s74\n ds_write_b32 %[lc], v94 offset:2304\n v_mov_b32 v94, s75\n ds_write_b32 %[lc], v94 offset:2560\n"
+            "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
+#endif
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
             : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf)
             : [ub] "v"(ublock), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end)
             : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
               "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "s40", "s41", "s42", "s43",
               "s44", "s45", "s46", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc",
+#if defined(WA_ASM_STAMPS)
+              "v94", "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
+#endif
               "m0", "memory");
+#if defined(WA_ASM_STAMPS)
+        if (dbg && lane == 0) {
+            const int32_t *lcs = tab + table + 64;
+            for (int i = 0; i < 6; i++) atomicAdd(&dbg[i], (unsigned long long)(uint32_t)lcs[(7 + i) * 64]);
+        }
+#endif
         if (code == 0) {   // a block of 64 path words is complete: one coalesced store, next block of draws
             path[(len - 64) + lane] = pbuf;
             if (cur == end) { exit_code = 2; break; }
@@ -659,6 +698,9 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         exit_code = code;
         break;
     }
+#if defined(WA_ASM_STAMPS)
+    if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
+#endif
     float L = exit_code == 1 ? INFINITY : ltab[len - 1];   // :78, one add of `precision` per step taken
     st.done = exit_code != 3;
     if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
@@ -890,7 +932,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #endif
     if (st.len < fast_limit && use_asm)
         wa_walk_fast_asm(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at, D.guard_bytes, D.ltab, st,
-                         flags_out, prefix_words);
+                         flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
