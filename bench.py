@@ -14,9 +14,16 @@ between barrier + synchronize pairs, inputs already resident in HBM (the per-pro
 pheromone init, heuristic field -- is outside the timed region and reported as setup_ms).
 
 Rank 0 prints one JSON line: metric/value (whole-job generations/s), `roofline` for the
-evaporation sweep (HIP events on the library's own stream, sampled inside the timed region),
-and -- at N = 1 -- `cpu_baseline`: the reference's own loop (oracle/_ref/ref_harness, kind
-"reference") or the C oracle (kind "port") timed on this host on a bounded sample.
+evaporation sweep and -- at N = 1 -- `cpu_baseline`: the reference's own loop (oracle/_ref/ref_harness,
+kind "reference") or the C oracle (kind "port") timed on this host on a bounded sample.
+
+roofline (the same at any --steps): after the timed region the sweep kernel itself, `k_evaporate`
+(ACSRank_3D.hpp:268-272: 48 B of algorithmic traffic per voxel), is launched 64 times on the library's own
+stream with per-dispatch HIP events (hipExtLaunchKernelGGL start/stop) at the BASELINE size 128^3 (two
+48 MiB buffers: inside the 256 MiB Infinity Cache) and at 256^3 (805 MB per launch: past it).  The headline
+`frac` is the 128^3 figure, `frac_256` stands beside it.  Inside the generation loop the sweep shares a
+launch with the latency-bound rank/mark blocks; that fused launch is reported separately (`fused_launch`,
+>= 32 samples whatever --steps is) and is NOT the roofline figure.
 """
 import argparse
 import json
@@ -44,12 +51,13 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary C5-shaped pair-planning measurement")
+    ap.add_argument("--no-roofline-256", action="store_true", help="skip the 256^3 (past the Infinity Cache) sweep measurement")
     ap.add_argument("--workload-index", type=int, default=None,
                     help="run rank R's C4 workload (grid seed 2024+R, colony seed 12345+R) on this GPU; default = own rank")
     return ap.parse_args()
 
 
-def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
+def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl):
     """Reported baseline (never the target).  Same grid, same parameters, first `cpu_gens`
     generations (the longest walks of the run); 1 thread like the reference."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -62,7 +70,7 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
     # cost check: the DEV-mode port draws the same numbers as the GPU, so best cost must be equal
     a = O.Acs(og)
     t0 = time.time()
-    tr = a.solve(sid, eid, G, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=12345, stream=0)
+    tr = a.solve(sid, eid, G, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
     t_port = time.time() - t0
     port_rate = G / t_port
     cost_equal = bool(np.array_equal(tr["bestL"].view(np.uint32), gpu_trace["bestL"][:G].view(np.uint32)))
@@ -75,7 +83,7 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
         os.makedirs(tmp, exist_ok=True)
         O.write_grid_in(og, tmp + "/grid.in")
         p = subprocess.run([O.REF_BIN, "acs", "gridin=%s/grid.in" % tmp, "spt=0,0,0", "ept=%d,%d,%d" % (n - 1, n - 1, n - 1),
-                            "seed=12345", "iters=%d" % G, "predict=%s" % PREDICT, "fixed=%d" % args.ants, "out=%s/o.waf" % tmp],
+                            "seed=%d" % wl["rng_seed"], "iters=%d" % G, "predict=%s" % PREDICT, "fixed=%d" % args.ants, "out=%s/o.waf" % tmp],
                            stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
         line = [l for l in p.stderr.splitlines() if l.startswith("{")]
         if p.returncode == 0 and line:
@@ -87,6 +95,27 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms):
             return out
     out["cpu_baseline"] = {"value": port_rate, "unit": "generations/s", "cores": 1, "kind": "port", "sample": sample}
     return out
+
+
+def sweep_roofline(ctx, n, repeats=64):
+    """k_evaporate alone on an n^3 field: 64 launches, each stamped by its own start/stop events."""
+    import numpy as np
+    from welding_robot_amd import api, synth
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    s = api.AcsSolver(ctx, grid, n_slots=1, max_colony=8, path_capacity=1024)
+    s.init_pheromone(1.0)
+    s.evaporate(0, 0.8, 4)           # warm-up launches (untimed)
+    s.sync()
+    s.profile(True, 1)
+    s.evaporate(0, 0.999, repeats)
+    pr = s.profile_read()["evaporate"]
+    s.close()
+    grid.close()
+    ms = pr["ms"] / max(pr["launches"], 1)
+    nbytes = 48.0 * n ** 3
+    return {"grid": n, "launches": pr["launches"], "avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes,
+            "achieved": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
 
 
 def pair_planning_extra(ctx, grid, free, n):
@@ -208,17 +237,26 @@ def main():
             assert np.array_equal(glob.view(np.uint32), trace["bestL"].view(np.uint32))
     best_all = wd.max_over_ranks(-float(cost), dev) * -1.0  # min over ranks
     if rank == 0:
-        ev = prof["evaporate"]
-        evap_ms = ev["ms"] / max(ev["launches"], 1)
-        alg_bytes = 48.0 * n ** 3  # 6 fp32 read + written per voxel
-        achieved = alg_bytes / (evap_ms * 1e-3) / 1e9 if evap_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot host
-        # rocprofv3 itself): FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate --pmc runs
+        # ---- fused launch (sweep + rank + mark share it): >= 32 per-dispatch samples whatever --steps is
+        fused = dict(prof["evaporate"])
+        if fused["launches"] < 32:   # continue the same search, untimed, every launch stamped
+            solver.profile(True, 1)
+            solver.run(32)
+            more = solver.profile_read()["evaporate"]
+            fused = {"ms": more["ms"], "launches": more["launches"]}
+        fused_ms = fused["ms"] / max(fused["launches"], 1)
+        # ---- the roofline kernel on its own, at the BASELINE size and past the Infinity Cache
+        r128 = sweep_roofline(ctx, n)
+        r256 = sweep_roofline(ctx, 256) if not args.no_roofline_256 else None
+        alg_bytes = r128["algorithmic_bytes_per_launch"]  # 6 fp32 read + written per voxel
+        achieved = r128["achieved"]
+        # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot host rocprofv3
+        # itself): only quoted when that file is about THIS kernel at THIS size
         traffic, traffic_src = None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["k_evaporate"]["grid"] == n:
-                traffic = float(pt["k_evaporate"]["fetch_bytes_corrected"] + pt["k_evaporate"]["write_bytes"])
+            if pt["kernel"] == "k_evaporate" and pt["grid"] == n:
+                traffic = float(pt["fetch_bytes_corrected"] + pt["write_bytes"])
                 traffic_src = pt["source"]
         except (OSError, KeyError, ValueError):
             pass
@@ -231,12 +269,19 @@ def main():
                                    "one independent problem per GPU (C4)" % (n, args.ants, K),
                        "grid": [n, n, n], "ants": args.ants, "generations": K, "problems_per_gpu": 1,
                        "global_best_allreduce": "RCCL MIN over ranks per generation, chunks of %d, async" % chunk if dist_on else "n/a (1 GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "k_evap_rank_mark (evaporation sweep; the rank/mark blocks of the same launch hide under it)",
+            "roofline": {"bound": "hbm", "kernel": "k_evaporate (the evaporation sweep, launched alone %d times after the timed region; "
+                                                   "per-dispatch HIP events on the library's stream)" % r128["launches"],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": evap_ms, "sampled_launches": ev["launches"],
+                         "avg_launch_ms": r128["avg_launch_ms"], "sampled_launches": r128["launches"],
+                         "note": "two 48 MiB buffers fit the 256 MiB Infinity Cache at this size; frac_256 is the past-the-cache figure",
+                         "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None,
+                         "sweep_256": r256,
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
+            "fused_launch": {"kernel": "k_evap_rank_mark (sweep + rank + deposit marks of one generation in one launch)",
+                             "avg_launch_ms": fused_ms, "sampled_launches": fused["launches"],
+                             "sweep_share_GBps": alg_bytes / (fused_ms * 1e-3) / 1e9 if fused_ms > 0 else 0.0},
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
             "setup_ms": setup_ms, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
@@ -253,7 +298,7 @@ def main():
             solver.run(G)
             solver.sync()
             gpu_first_ms = (time.perf_counter() - t1) * 1e3
-            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms))
+            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl))
         if world == 1 and not args.no_extras:
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
         print(json.dumps(out), flush=True)

@@ -45,6 +45,11 @@ typedef struct wa_bspline wa_bspline;
 
 /* ---- context --------------------------------------------------------------------------- */
 const char *wa_version(void);
+/* visible HIP devices (0 when there is none or no runtime): the drop-in ACS_Rank shards its pair searches over all of
+ * them, one wa_ctx per device (ACSRank_3D.hpp:472-499 is a loop over independent searches) */
+int wa_device_count(void);
+/* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling
+ * thread's current HIP device, and restores the caller's current device before returning. */
 int wa_ctx_create(int device_ordinal, wa_ctx **out);
 void wa_ctx_destroy(wa_ctx *ctx);
 const char *wa_last_error(const wa_ctx *ctx);

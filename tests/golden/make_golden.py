@@ -85,6 +85,42 @@ def gen_smooth():
         print("smooth", fill, len(pr["g_path_x"]), pr["s2_samples"].reshape(-1, 3)[[0, 60, -1]])
 
 
+def gen_synth128():
+    """synthetic 128^3 grid of BASELINE config C3 (our own PRNG), entering the reference through readGridMap"""
+    g = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    gin = TMP + "/synth128.in"
+    O.write_grid_in(g, gin)
+    for tag, kw in [("acs_synth128_adaptive10", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=10, predict="731.43", driven=1)),
+                    ("acs_synth128_fixed256_4", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=4, predict="731.43", fixed=256)),
+                    ("acs_synth128_fixed256_40", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=40, predict="731.43", fixed=256))]:
+        a = O.run_ref("acs", TMP + "/a.waf", **kw)
+        out = keep(a, ACS_KEYS)
+        out["args"] = np.frombuffer(repr(sorted((k, str(v)) for k, v in kw.items() if k != "gridin")).encode(), np.uint8)
+        out["grid_seed"] = np.array([2024], np.int64)
+        out["grid_free_count"] = np.array([int(g.free.sum())], np.int64)
+        out["grid_fnv"] = np.array([O.fnv1a_bytes(g.free.tobytes()) - (1 << 64) if O.fnv1a_bytes(g.free.tobytes()) >= (1 << 63) else O.fnv1a_bytes(g.free.tobytes())], np.int64)
+        waf.save(HERE + "/%s.waf" % tag, out)
+        print(tag, a["best_L"], a["tr_colony"], a["tr_steps"])
+
+
+
+def gen_gridfile():
+    """The grid-map text cache: the file the reference WRITES for cubic.stl
+    (model_grid_map.hpp:275-294, with the last-triangle bounding box and "%f" of Q5) and what the reference's own
+    readGridMap (:300-356) rebuilds from that file -- which is not the grid that was written."""
+    cubic = os.path.join(HERE, "cubic.stl")
+    gf = TMP + "/cubic_grid_ref.in"
+    made = O.run_ref("voxelize", TMP + "/vg.waf", stl=cubic, p="0.0219", wall=8, gridout=gf)
+    back = O.run_ref("voxelize", TMP + "/vr.waf", gridin=gf)
+    out = {"file_text": np.frombuffer(open(gf, "rb").read(), np.uint8).copy(),
+           "made_dims": made["dims"], "made_precision": made["precision"], "made_cx": made["cx"], "made_cy": made["cy"],
+           "made_cz": made["cz"], "made_free_packed": np.packbits(made["free"]),
+           "read_dims": back["dims"], "read_precision": back["precision"], "read_cx": back["cx"], "read_cy": back["cy"],
+           "read_cz": back["cz"], "read_free_packed": np.packbits(back["free"])}
+    waf.save(HERE + "/gridfile_cubic.waf", out)
+    print("gridfile_cubic.waf: %d bytes of file text, dims %s" % (out["file_text"].size, made["dims"][:3].tolist()))
+
+
 def gen_nb26():
     """reference member functions on 26-neighbour adjacency (harness nb=26, always driven)."""
     cubic = os.path.join(HERE, "cubic.stl")
@@ -122,6 +158,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "nb26":
         gen_nb26()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "synth128":
+        gen_synth128()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "gridfile":
+        gen_gridfile()
         return
     for f in ("cubic.stl", "simplified_piece.stl"):
         shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))
@@ -168,20 +210,7 @@ def main():
         waf.save(HERE + "/%s.waf" % tag, out)
         print(tag, a["best_L"], len(a["best_path"]))
 
-    # ---- synthetic 128^3 (KA3-style, our own PRNG) -------------------------------------------
-    g = O.synth_grid(128, seed=2024, occ_prob=0.10)
-    gin = TMP + "/synth128.in"
-    O.write_grid_in(g, gin)
-    for tag, kw in [("acs_synth128_adaptive10", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=10, predict="731.43", driven=1)),
-                    ("acs_synth128_fixed256_4", dict(gridin=gin, spt="0,0,0", ept="127,127,127", seed=12345, iters=4, predict="731.43", fixed=256))]:
-        a = O.run_ref("acs", TMP + "/a.waf", **kw)
-        out = keep(a, ACS_KEYS)
-        out["args"] = np.frombuffer(repr(sorted((k, str(v)) for k, v in kw.items() if k != "gridin")).encode(), np.uint8)
-        out["grid_seed"] = np.array([2024], np.int64)
-        out["grid_free_count"] = np.array([int(g.free.sum())], np.int64)
-        out["grid_fnv"] = np.array([O.fnv1a_bytes(g.free.tobytes()) - (1 << 64) if O.fnv1a_bytes(g.free.tobytes()) >= (1 << 63) else O.fnv1a_bytes(g.free.tobytes())], np.int64)
-        waf.save(HERE + "/%s.waf" % tag, out)
-        print(tag, a["best_L"], a["tr_colony"], a["tr_steps"])
+    gen_synth128()
 
     # ---- pair flow + GTSP on cubic (main.cpp:279-283) --------------------------------------------
     vg = O.run_ref("voxelize", TMP + "/v.waf", stl=cubic, p="0.0219", wall=8)
@@ -223,6 +252,7 @@ def main():
     gen_bspline()
     gen_smooth()
     gen_nb26()
+    gen_gridfile()
 
 
 if __name__ == "__main__":

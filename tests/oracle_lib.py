@@ -213,6 +213,33 @@ def write_grid_in(grid, path, lo=None, hi=None):
             f.write(" ".join("1" if v else "0" for v in row) + " \n")
 
 
+def q5_bbox(tris, precision):
+    """What GridMap's min_*/max_* members hold when creatGridMap writes its file: the LAST triangle's
+    bounding box -+ precision, in float arithmetic (model_grid_map.hpp:228-248)."""
+    v = np.ascontiguousarray(tris, np.float32)[-1, 3:12].reshape(3, 3)
+    p = np.float32(precision)
+    return (v.min(axis=0) - p).astype(np.float32), (v.max(axis=0) + p).astype(np.float32)
+
+
+def read_grid_in(path):
+    """GridMap::readGridMap restated (model_grid_map.hpp:300-356): header, per-axis coordinates from the header's
+    box (:321-328 == wo_axis_coords), then one int per voxel in raster z,y,x order; a voxel whose token is missing
+    stays free (the reference ignores fscanf's result).  Returns (Grid, voxel tokens read)."""
+    tok = open(path, "rb").read().split()
+    ms, rx, ry, rz = (int(t) for t in tok[:4])
+    prec, wall = np.float32(tok[4].decode()), int(tok[5])
+    box = [np.float32(t.decode()) for t in tok[6:12]]
+    ax = []
+    for c, n in enumerate((rx, ry, rz)):
+        out = np.empty(n, np.float32)
+        lib().wo_axis_coords(C.c_float(box[c]), C.c_float(box[3 + c]), C.c_float(prec), wall, n, out.ctypes.data)
+        ax.append(out)
+    vals = tok[12:12 + rx * ry * rz]
+    free = np.ones(rx * ry * rz, np.uint8)
+    free[:len(vals)] = [1 if int(t) else 0 for t in vals]
+    return Grid(ax[0], ax[1], ax[2], free, prec, wall), len(vals)
+
+
 class Acs:
     def __init__(self, grid, pheromone_0=1.0, nb=6):
         self.grid, self.nb = grid, nb

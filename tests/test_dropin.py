@@ -109,3 +109,25 @@ def test_dropin_pipeline_dev_mode_is_deterministic_and_sane():
     # the correct (non-compat) graph file parses back to the in-memory matrix
     tok = open(a + ".graph").read().split()
     assert tok[:2] == ["5", "10"] and np.float32(tok[2]) == da["cost"][(0, 1)]
+
+
+@pytest.mark.gpu
+def test_pair_loop_sharded_over_contexts_is_shard_invariant():
+    """searchBestPathOfPoints' pair loop (ACSRank_3D.hpp:472-499) on one, two and three contexts -- host threads, a
+    wa_ctx + grid replica + solver each, pairs dealt round-robin, stream key = global pair index -- gives the same
+    costs and the same paths, bit for bit.  (One GPU here: an ordinal listed twice means two contexts on it.)"""
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
+                        os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
+    outs = {}
+    for devs in ("0", "0,0", "0,0,0", "all"):
+        out = "/tmp/weldacs_shard_%s.txt" % devs.replace(",", "_")
+        rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", devs, out],
+                            capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
+        outs[devs] = open(out, "rb").read()
+    assert outs["0"].count(b"pair ") == 10 and b"7f800000" not in outs["0"]      # 10 finite pair costs
+    assert outs["0"] == outs["0,0"] == outs["0,0,0"] == outs["all"]

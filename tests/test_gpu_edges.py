@@ -128,32 +128,6 @@ def test_exact_path_capacity_and_reuse_of_a_solver(ctx):
     assert s.result()[1].tolist() == [4, 3, 2, 1, 0] and np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
 
 
-def test_hipgraph_replay_equals_plain_launches(ctx):
-    """WA_GRAPH=G captures G generations of the fused loop once and replays them (kernels read the generation
-    number from a device counter).  Odd chunk sizes exercise the buffer-parity and counter realignment paths."""
-    og = box_grid(12, 12, 12, occ_prob=0.12, seed=3)
-    og.free[0] = og.free[-1] = 1
-    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, 1.0, 0)
-    p = api.default_params(max_iteration=61, predict=60.0, fixed_colony=20, rng_mode=api.RNG_DEV, seed=5)
-    a = api.AcsSolver(ctx, dg, 1, 20)
-    a.reset_pheromone(1.0)                       # reset() semantics on both sides (out-of-bounds edges hold p0 too)
-    a.solve(p, 0, og.n - 1)
-    os.environ["WA_GRAPH"] = "4"
-    try:
-        b = api.AcsSolver(ctx, dg, 1, 20)
-    finally:
-        del os.environ["WA_GRAPH"]
-    for rounds in range(2):                      # the second begin() must rebuild the graph
-        b.reset_pheromone(1.0)
-        b.begin(p, 0, og.n - 1)
-        for chunk in (3, 9, 1, 8, 5, 4, 31):
-            b.run(chunk)
-        b.sync()
-        assert np.array_equal(bits(a.pheromone()), bits(b.pheromone())) and np.array_equal(a.result()[1], b.result()[1])
-        ta, tb = a.trace(), b.trace()
-        assert np.array_equal(bits(ta["bestL"]), bits(tb["bestL"])) and np.array_equal(ta["steps"], tb["steps"])
-
-
 def test_stepwise_run_equals_single_solve(ctx):
     og = box_grid(12, 12, 12, occ_prob=0.12, seed=3)
     og.free[0] = og.free[-1] = 1
@@ -168,3 +142,61 @@ def test_stepwise_run_equals_single_solve(ctx):
     b.sync()
     assert np.array_equal(bits(a.pheromone()), bits(b.pheromone())) and np.array_equal(a.result()[1], b.result()[1])
     assert np.array_equal(bits(a.trace()["bestL"]), bits(b.trace()["bestL"]))
+
+
+def test_slot_that_sat_out_an_odd_number_of_generations_is_reused_without_reset(ctx):
+    """The sweep is double-buffered and flips the current buffer for the whole solver, but only the ACTIVE slots are
+    swept: after an odd number of generations an idle slot's field still lives in the other buffer.  A later search
+    that uses it without re-initialising must see that field (here: slot 1's init values), not the other buffer's
+    stale contents -- which were all-zero, i.e. 'every edge free and in bounds'."""
+    og = box_grid(12, 10, 9, occ_prob=0.12, seed=5)
+    og.free[0] = og.free[-1] = 1
+    n = 12 * 10 * 9
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, n_slots=2, max_colony=12)
+    s.init_pheromone(1.0)
+    p1 = api.default_params(max_iteration=7, predict=40.0, fixed_colony=12, rng_mode=api.RNG_DEV, seed=21)   # odd
+    s.solve(p1, [0], [n - 1], streams=[5])
+    p2 = api.default_params(max_iteration=6, predict=40.0, fixed_colony=12, rng_mode=api.RNG_DEV, seed=22)
+    s.solve(p2, [0, n - 1], [n - 1, 0], streams=[8, 9])                                                      # no reset in between
+    a0, a1 = O.Acs(og), O.Acs(og)
+    a0.solve(0, n - 1, 7, 40.0, fixed_colony=12, mode=O.DEV, seed=21, stream=5)
+    tr0 = a0.solve(0, n - 1, 6, 40.0, fixed_colony=12, mode=O.DEV, seed=22, stream=8)   # carries slot 0's field over
+    tr1 = a1.solve(n - 1, 0, 6, 40.0, fixed_colony=12, mode=O.DEV, seed=22, stream=9)   # slot 1: still the init field
+    for q, (a, tr) in enumerate(((a0, tr0), (a1, tr1))):
+        t = s.trace(q)
+        assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), q
+        assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), q
+    # ... and an idle slot can still be read back while the others moved on (an odd number of generations again)
+    s.solve(p1, [0], [n - 1], streams=[5])
+    assert np.array_equal(bits(s.pheromone(1)), bits(a1.pheromone()))
+
+
+def test_every_ant_of_a_generation_matches_the_oracle(ctx):
+    """agents[] of the last generation (ACSRank_3D.hpp:251-261): L and node count per ant, not only the best."""
+    og = box_grid(20, 17, 15, occ_prob=0.1, seed=3)
+    og.free[0] = og.free[-1] = 1
+    n = 20 * 17 * 15
+    for gens in (1, 4):
+        s, a, t = run_both(ctx, og, 0, n - 1, gens, 90.0, fixed=31, seed=13, stream=2)
+        L, lens = s.ants()
+        olens, oL = a.last_ants()
+        assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL))
+
+
+def test_hand_scheduled_walk_loop_equals_the_compiler_scheduled_one(ctx):
+    """WA_WALK_ASM=0 keeps the C++ loop: both must give the same ants, the same field, the same trace."""
+    og = box_grid(24, 24, 24, occ_prob=0.1, seed=8)
+    og.free[0] = og.free[-1] = 1
+    n = 24 ** 3
+    res = []
+    for knob in ("1", "0"):
+        os.environ["WA_WALK_ASM"] = knob
+        try:
+            s, a, t = run_both(ctx, og, 0, n - 1, 25, 200.0, fixed=64, seed=77)
+            res.append((s.ants(), s.pheromone(), t))
+        finally:
+            del os.environ["WA_WALK_ASM"]
+    (x, px, tx), (y, py, ty) = res
+    assert np.array_equal(x[1], y[1]) and np.array_equal(bits(x[0]), bits(y[0])) and np.array_equal(bits(px), bits(py))
+    assert np.array_equal(tx["steps"], ty["steps"])

@@ -56,8 +56,6 @@ struct WaAcsDev {
     int32_t *dcount;               // [slot][2]
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
-    int32_t *genbase;              // device generation counter: kernels of the fused DEV loop run generation *genbase + gen_off,
-                                   // which lets a captured hipGraph of G generations be replayed (the graph's last kernel adds G)
 };
 
 // path word = voxel id | (edge index taken to arrive << SHIFT)
@@ -151,7 +149,6 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     D.ctl[slot] = c;
 }
 
-__global__ void k_set_genbase(WaAcsDev D, int32_t v) { *D.genbase = v; }
 
 // L as a function of the step count: Agent::addNextNode adds `distance` (== precision for face moves, :378) once per
 // step (:78), sequentially in fp32 -- not i * precision.  One wavefront runs the chain, lane l keeps entry 64c + l.
@@ -1046,13 +1043,10 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 // the table depends on -- and blocks [TB, TB + 8*64) are the ordinary apply pass, which skips exactly
 // those edges.  The two roles touch disjoint edges, so no ordering between them is needed.
 #define WA_TABLE_BLOCKS 32
-__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_t advance)
+__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
 {
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y;
-    // last launch of a captured graph of `advance` generations: move the device generation counter on (no block of
-    // this launch reads it; the next launch is ordered after this one)
-    if (advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *D.genbase += advance;
     // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
     if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
     if ((int32_t)blockIdx.x < WA_TABLE_BLOCKS) {
@@ -1073,12 +1067,11 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
 template <bool ALPHA1, bool SPARSE>
-__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen_off, int32_t walk_flags)
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
-    const int32_t gen = *D.genbase + gen_off;
     const int32_t colony = c->colony[gen & 1];
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
@@ -1395,24 +1388,9 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 // ------------------------------------------------------------------ the evaporation sweep body
 // :268-272 -- dst = src * rho over n_floats values; float4 per lane, 4 independent float4 in flight per
 // thread, grid-stride over E blocks.  One definition for k_evaporate and the fused k_evap_rank_mark.
-// WA_NT_LOAD / WA_NT_STORE (experiment builds): non-temporal hints on the stream.
 typedef float wa_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p)
-{
-#ifdef WA_NT_LOAD
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v)
-{
-#ifdef WA_NT_STORE
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p) { return *p; }
+__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v) { *p = v; }
 __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
 {
     const wa_v4f *s4 = reinterpret_cast<const wa_v4f *>(src);
@@ -1446,7 +1424,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
 template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen_off, int32_t MB)
+                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -1464,7 +1442,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
             uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
             const int32_t n0 = D.dcount[slot * 2];
-            const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)(*D.genbase + gen_off);
+            const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)gen;
             const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
             const float rho = R.rho;
             const int64_t first = (int64_t)(evap_now % WA_LAZY_PERIOD);
@@ -1481,7 +1459,6 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     }
     // ---- rank + mark
     const int32_t mb = (int32_t)blockIdx.x;  // 0..511: (bx = mb & 7, rank bit = mb >> 3)
-    const int32_t gen = *D.genbase + gen_off;
     WaSlotCtl *ctl = &D.ctl[slot];
     const int32_t colony = ctl->colony[gen & 1];
     const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];

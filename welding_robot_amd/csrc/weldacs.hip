@@ -22,9 +22,7 @@
 // ------------------------------------------------------------------ handles
 struct wa_ctx {
     int device;
-    hipStream_t stream;    // main stream: every kernel except the overlapped evaporation sweep
-    hipStream_t stream2;   // evaporation sweep of generation g runs here, concurrently with walk g
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t stream;    // every kernel of this context
     std::string err;
     hipDeviceProp_t prop;
 };
@@ -58,17 +56,14 @@ struct wa_acs {
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     float *pher_alloc[2], *heur_alloc;   // the allocations behind pher_buf[] / D.heur (fields + guard bands)
     int cur_buf;
+    std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     WaRun R;
-    bool begun, overlap_walk, overlap_rank, fuse, inplace, fuse_table;
+    bool begun;
     bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
     std::vector<int> lazy_mode;         // per slot: init mode of the stored records (-1 unknown)
     std::vector<float> lazy_p0;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
-    // hipGraph of `graph_len` generations of the fused DEV loop (0 = off), valid for the run begun last
-    int32_t graph_len, graph_buf0, genbase_host;
-    hipGraph_t graph;
-    hipGraphExec_t graph_exec;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
     // profiling
@@ -94,6 +89,25 @@ static int fail(wa_ctx *c, int code, const char *fmt, const char *a = "")
         if (e_ != hipSuccess) return fail((ctx), WA_ERR_DEVICE, #call ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point runs on the device of its context, whatever device the calling thread had current (another
+// context on another GPU, torch.cuda.set_device ...), and leaves the caller's current device as it found it.
+struct WaDevGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit WaDevGuard(const wa_ctx *c)
+    {
+        if (!c) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) {
+            ok = hipSetDevice(c->device) == hipSuccess;
+            switched = ok && prev >= 0;
+        }
+    }
+    ~WaDevGuard() { if (switched) hipSetDevice(prev); }
+    WaDevGuard(const WaDevGuard &) = delete;
+    WaDevGuard &operator=(const WaDevGuard &) = delete;
+};
+
 template <class T>
 static hipError_t dalloc(T **p, size_t count)
 {
@@ -116,27 +130,28 @@ int wa_ctx_create(int device_ordinal, wa_ctx **out)
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return WA_ERR_DEVICE;
-    if (hipSetDevice(device_ordinal) != hipSuccess) return WA_ERR_DEVICE;
     wa_ctx *c = new wa_ctx();
     c->device = device_ordinal;
-    if (hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    WaDevGuard dev_guard_(c);   // streams and events are created on the context's device; the caller's current device is restored
+    if (!dev_guard_.ok ||
+        hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return WA_ERR_DEVICE;
     }
     *out = c;
     return WA_OK;
 }
+int wa_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 void wa_ctx_destroy(wa_ctx *c)
 {
     if (!c) return;
+    WaDevGuard dev_guard_(c);
     hipStreamDestroy(c->stream);
-    hipStreamDestroy(c->stream2);
-    hipEventDestroy(c->ev_fork);
-    hipEventDestroy(c->ev_join);
     delete c;
 }
 const char *wa_last_error(const wa_ctx *c) { return c ? c->err.c_str() : "no context"; }
@@ -148,8 +163,8 @@ int wa_ctx_device_name(const wa_ctx *c, char *buf, size_t cap)
 }
 int wa_ctx_sync(wa_ctx *c)
 {
+    WaDevGuard dev_guard_(c);
     if (!c) return WA_ERR_ARG;
-    HIPC(c, hipStreamSynchronize(c->stream2));
     HIPC(c, hipStreamSynchronize(c->stream));
     return WA_OK;
 }

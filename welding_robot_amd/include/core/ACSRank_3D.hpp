@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <thread>
 #include <set>
 #include <unordered_map>
 
@@ -121,6 +122,11 @@ public:
     void setLazyEvaporation(bool b) { lazy = b; }
     void setGraphFileCompat(bool b) { graph_compat = b; }
     void setConcurrentPairs(int n) { concurrent_pairs = n; }
+    // The pair loop (:472-499) is a loop over independent searches: in DEV mode it is sharded round-robin over
+    // these devices, one host thread + one wa_ctx (+ a replica of the grid) per entry.  Every pair keeps its GLOBAL
+    // index as stream key, so the cost matrix and the paths do not depend on the number of shards.  Default: every
+    // visible device (wa_device_count()).  An ordinal may be listed twice (two contexts on one GPU).
+    void setDevices(const std::vector<int> &ordinals) { devices = ordinals; devices_set = true; }
     int lastStatus() const { return last_status; }
     const std::vector<float> &cost_matrix() const { return costs; }
 
@@ -180,25 +186,87 @@ public:
         p.rng_mode = rng_mode;
         p.seed = seed;
         std::vector<float> order_costs;
-        const int batch = rng_mode == WA_RNG_REF ? 1 : slots;
-        for (size_t b0 = 0; b0 < pairs.size(); b0 += batch) {
-            int nb = (int)std::min<size_t>(batch, pairs.size() - b0);
-            std::vector<int64_t> s0(nb), e0(nb);
-            std::vector<uint32_t> st(nb);
-            for (int q = 0; q < nb; q++) { s0[q] = ids[pairs[b0 + q].first]; e0[q] = ids[pairs[b0 + q].second]; st[q] = (uint32_t)(b0 + q); }
-            int rc = wa_acs_solve(solver, &p, nb, s0.data(), e0.data(), st.data());  // computeSolution :480
-            if (rc == WA_OK) rc = wa_acs_reset_pheromone(solver, -1, p.pheromone_0);  // reset() :481
-            if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(weldacs_dropin::context())); last_status = rc; return; }
-            for (int q = 0; q < nb; q++) {
-                int i = pairs[b0 + q].first, j = pairs[b0 + q].second;
-                fetch_best(q);  // `best` keeps its previous path when no ant arrived (Q9)
-                best_matrix[i][j] = best;
-                best_matrix[j][i] = best;
-                costs[(size_t)i * point_num + j] = costs[(size_t)j * point_num + i] = best.L;
-                order_costs.push_back(best.L);
-                printf("[ACS 3D] <Point (%.3f, %.3f, %.3f) : Point (%.3f, %.3f, %.3f)> Path length: %.3f\r\n", route_points[i].x,
-                       route_points[i].y, route_points[i].z, route_points[j].x, route_points[j].y, route_points[j].z, best.L);
+        // ---- the searches: one shard per device (DEV mode), the primary context's solver is shard 0
+        std::vector<int> devs;
+        if (rng_mode == WA_RNG_DEV) {
+            if (devices_set) devs = devices;
+            else for (int d = 0, n = wa_device_count(); d < n; d++) devs.push_back(d);
+        }
+        if (devs.size() > pairs.size()) devs.resize(pairs.size());
+        if (devs.empty()) devs.push_back(weldacs_dropin::device_ordinal());
+        const int D = (int)devs.size();
+        std::vector<PairResult> res(pairs.size());
+        std::vector<int> shard_rc(D, WA_OK);
+        std::vector<std::string> shard_err(D);
+        auto run_shard = [&](int d, wa_ctx *ctx, wa_acs *sv) {
+            const int batch = rng_mode == WA_RNG_REF ? 1 : slots;
+            std::vector<size_t> mine;
+            for (size_t k = (size_t)d; k < pairs.size(); k += (size_t)D) mine.push_back(k);
+            for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
+                int nb = (int)std::min<size_t>(batch, mine.size() - b0);
+                std::vector<int64_t> s0(nb), e0(nb);
+                std::vector<uint32_t> st(nb);
+                for (int q = 0; q < nb; q++) { size_t k = mine[b0 + q]; s0[q] = ids[pairs[k].first]; e0[q] = ids[pairs[k].second]; st[q] = (uint32_t)k; }
+                int rc = wa_acs_solve(sv, &p, nb, s0.data(), e0.data(), st.data());  // computeSolution :480
+                if (rc == WA_OK) rc = wa_acs_reset_pheromone(sv, -1, p.pheromone_0);  // reset() :481
+                for (int q = 0; q < nb && rc == WA_OK; q++) {
+                    PairResult &r = res[mine[b0 + q]];
+                    int64_t len = 0;
+                    rc = wa_acs_result(sv, q, &r.cost, &len, NULL, NULL, 0);
+                    if (rc == WA_OK && len > 0) {
+                        r.ids.resize((size_t)len); r.ch.resize((size_t)len);
+                        rc = wa_acs_result(sv, q, &r.cost, &len, r.ids.data(), r.ch.data(), len);
+                    }
+                }
+                if (rc != WA_OK) { shard_rc[d] = rc; shard_err[d] = wa_last_error(ctx); return; }
             }
+        };
+        if (D == 1) {
+            run_shard(0, weldacs_dropin::context(), solver);
+        } else {
+            // replicas: occupancy and axis coordinates from the host mirror, one context + grid + solver per extra shard
+            std::vector<uint8_t> fr((size_t)size_of_map());
+            std::vector<float> ax((size_t)rangeX), ay((size_t)rangeY), az((size_t)rangeZ);
+            Vertex3<float> ***m = ptr_grid_map();
+            for (int z = 0, id = 0; z < rangeZ; z++)
+                for (int y = 0; y < rangeY; y++)
+                    for (int x = 0; x < rangeX; x++, id++) fr[(size_t)id] = m[z][y][x].isFree ? 1 : 0;
+            for (int x = 0; x < rangeX; x++) ax[x] = m[0][0][x].pt.x;
+            for (int y = 0; y < rangeY; y++) ay[y] = m[0][y][0].pt.y;
+            for (int z = 0; z < rangeZ; z++) az[z] = m[z][0][0].pt.z;
+            std::vector<wa_ctx *> cs(D, (wa_ctx *)NULL);
+            std::vector<wa_grid *> gs(D, (wa_grid *)NULL);
+            std::vector<wa_acs *> ss(D, (wa_acs *)NULL);
+            cs[0] = weldacs_dropin::context(); ss[0] = solver;
+            for (int d = 1; d < D; d++) {
+                int rc = wa_ctx_create(devs[d], &cs[d]);
+                if (rc == WA_OK) rc = wa_grid_from_occupancy(cs[d], fr.data(), rangeX, rangeY, rangeZ, ax.data(), ay.data(), az.data(), precision, wall, &gs[d]);
+                if (rc == WA_OK) rc = make_solver(cs[d], gs[d], predict_path_len, &ss[d]);
+                if (rc != WA_OK) { shard_rc[d] = rc; shard_err[d] = cs[d] ? wa_last_error(cs[d]) : "wa_ctx_create failed"; }
+            }
+            std::vector<std::thread> th;
+            for (int d = 1; d < D; d++)
+                if (shard_rc[d] == WA_OK) th.emplace_back(run_shard, d, cs[d], ss[d]);
+            run_shard(0, cs[0], ss[0]);
+            for (auto &t : th) t.join();
+            for (int d = 1; d < D; d++) {
+                if (ss[d]) wa_acs_destroy(ss[d]);
+                if (gs[d]) wa_grid_destroy(gs[d]);
+                if (cs[d]) wa_ctx_destroy(cs[d]);
+            }
+        }
+        for (int d = 0; d < D; d++)
+            if (shard_rc[d] != WA_OK) { printf("[ACS 3D] shard %d (device %d): %s\n", d, devs[d], shard_err[d].c_str()); last_status = shard_rc[d]; return; }
+        // ---- gather in the reference's pair order (`best` keeps its previous path when no ant arrived, Q9)
+        for (size_t k = 0; k < pairs.size(); k++) {
+            const int i = pairs[k].first, j = pairs[k].second;
+            adopt_best(res[k]);
+            best_matrix[i][j] = best;
+            best_matrix[j][i] = best;
+            costs[(size_t)i * point_num + j] = costs[(size_t)j * point_num + i] = best.L;
+            order_costs.push_back(best.L);
+            printf("[ACS 3D] <Point (%.3f, %.3f, %.3f) : Point (%.3f, %.3f, %.3f)> Path length: %.3f\r\n", route_points[i].x,
+                   route_points[i].y, route_points[i].z, route_points[j].x, route_points[j].y, route_points[j].z, best.L);
         }
         if (rng_mode == WA_RNG_REF) {  // hand the libc stream on to ACS_GTSP, as the process-global rand() does
             wa_acs_rand_state(solver, weldacs_dropin::rand_state(), 0);
@@ -276,6 +344,9 @@ public:
     }
 
 private:
+    struct PairResult { float cost = 0; std::vector<int32_t> ids; std::vector<int8_t> ch; };
+    std::vector<int> devices;
+    bool devices_set = false;
     wa_acs *solver = NULL;
     int slots = 1;
     int rng_mode = WA_RNG_DEV, max_iteration = 150, fixed_colony = 0, concurrent_pairs = 16, neighbourhood = 6;
@@ -297,17 +368,36 @@ private:
         if (!ctx || !device_grid()) { last_status = WA_ERR_STATE; return false; }
         if (solver) { wa_acs_destroy(solver); solver = NULL; }
         if (!seeded) seed = (uint64_t)time(0);  // :327
-        int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
-        if (colony < 1) colony = 1;
-        slots = rng_mode == WA_RNG_REF ? 1 : std::max(1, concurrent_pairs);
-        const bool lazy_ok = lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64;
-        int rc = lazy_ok ? wa_acs_create_lazy(ctx, device_grid(), slots, colony, 0, &solver)
-                         : wa_acs_create_nb(ctx, device_grid(), slots, colony, 0, neighbourhood, &solver);
+        int rc = make_solver(ctx, device_grid(), predict, &solver);
         if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(ctx)); last_status = rc; return false; }
         wa_acs_init_pheromone(solver, -1, 1.0f);
         if (rng_mode == WA_RNG_REF) wa_acs_srand(solver, (uint32_t)seed);
         printf("[ACS 3D] Created %d nodes, node cubiod [x: %d, y: %d, z: %d]\r\n", size_of_map(), rangeX, rangeY, rangeZ);
         return true;
+    }
+    // one solver for this grid on `ctx` (the primary context or a shard's)
+    int make_solver(wa_ctx *ctx, wa_grid *g, float predict, wa_acs **out)
+    {
+        int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
+        if (colony < 1) colony = 1;
+        slots = rng_mode == WA_RNG_REF ? 1 : std::max(1, concurrent_pairs);
+        const bool lazy_ok = lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64;
+        int rc = lazy_ok ? wa_acs_create_lazy(ctx, g, slots, colony, 0, out) : wa_acs_create_nb(ctx, g, slots, colony, 0, neighbourhood, out);
+        if (rc == WA_OK) rc = wa_acs_init_pheromone(*out, -1, 1.0f);
+        return rc;
+    }
+    void adopt_best(const PairResult &r)
+    {
+        const size_t len = r.ids.size();
+        if (len > 0) {
+            std::vector<ACS_Node<float> *> p(len);
+            std::vector<int> idx(len - 1);
+            for (size_t i = 0; i < len; i++) p[i] = node(r.ids[i]);
+            for (size_t i = 0; i + 1 < len; i++) idx[i] = r.ch[i];
+            best.assign(p, idx, r.cost);
+        } else {
+            best.L = r.cost;  // +inf: path left as it was (Q9)
+        }
     }
     ACS_Node<float> *node(int32_t id)
     {

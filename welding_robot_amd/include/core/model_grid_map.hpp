@@ -84,8 +84,19 @@ public:
         }
         float bbox[6];
         int rc = wa_grid_from_mesh(ctx, tris.data(), (int64_t)mesh.size(), precision, wall, &grid_h, bbox);
+        last_status = rc;
         if (rc != WA_OK) { printf("[Grid Map] %s\n", wa_last_error(ctx)); return NULL; }
         min_x = bbox[0]; min_y = bbox[1]; min_z = bbox[2]; max_x = bbox[3]; max_y = bbox[4]; max_z = bbox[5];
+        {   // what the reference's members hold when it writes its file: the LAST triangle's bounding box
+            // +- precision (model_grid_map.hpp:228-248 reuse min_*/max_* as scratch inside the triangle loop)
+            const Triangles<T> &t = mesh.back();
+            T lo[3] = {t.vertex[0].x, t.vertex[0].y, t.vertex[0].z}, hi[3] = {lo[0], lo[1], lo[2]};
+            for (int i = 0; i < 3; i++) {
+                const T c[3] = {t.vertex[i].x, t.vertex[i].y, t.vertex[i].z};
+                for (int a = 0; a < 3; a++) { hi[a] = c[a] > hi[a] ? c[a] : hi[a]; lo[a] = c[a] < lo[a] ? c[a] : lo[a]; }
+            }
+            for (int a = 0; a < 3; a++) { q5_lo[a] = lo[a] - precision; q5_hi[a] = hi[a] + precision; }
+        }
         printf("[Grid Map]max(%.2f, %.2f, %.2f), min(%.2f, %.2f, %.2f) \n", max_x, max_y, max_z, min_x, min_y, min_z);
         printf("[Grid Map] %d triangles is scanned... \n", (int)mesh.size());
         materialise();
@@ -95,18 +106,24 @@ public:
         return grid_map;
     }
 
+    // Reads the reference's own files and this header's.  A file whose voxel list is shorter than its header announces
+    // is an error (the reference keeps reading with a failing fscanf and leaves the remaining voxels free).
     void readGridMap(std::string file_name)
     {
+        last_status = WA_OK;
         FILE *fp = fopen(file_name.c_str(), "r");
         if (fp == NULL) {
+            last_status = WA_ERR_FILE;
             std::cout << "[Grid Map] Failed to read file, skipping..." << std::endl;
             return;
         }
         release();
         int rx, ry, rz, ms;
         if (fscanf(fp, "%d %d %d %d %f %d", &ms, &rx, &ry, &rz, &precision, &wall) != 6 ||
-            fscanf(fp, "%f %f %f %f %f %f", &min_x, &min_y, &min_z, &max_x, &max_y, &max_z) != 6 || rx < 1 || ry < 1 || rz < 1) {
+            fscanf(fp, "%f %f %f %f %f %f", &min_x, &min_y, &min_z, &max_x, &max_y, &max_z) != 6 || rx < 1 || ry < 1 || rz < 1 ||
+            !(precision > 0) || wall < 0) {
             fclose(fp);
+            last_status = WA_ERR_FORMAT;
             std::cout << "[Grid Map] Malformed grid file, skipping..." << std::endl;
             return;
         }
@@ -115,16 +132,22 @@ public:
         wa_axis_coords(min_y, max_y, precision, wall, ry, cy.data());
         wa_axis_coords(min_z, max_z, precision, wall, rz, cz.data());
         std::vector<uint8_t> fr((size_t)rx * ry * rz, 1);
-        for (size_t i = 0; i < fr.size(); i++) {
+        size_t got = 0;
+        for (; got < fr.size(); got++) {
             int v = 1;
             if (fscanf(fp, "%d", &v) != 1) break;
-            fr[i] = v ? 1 : 0;
+            fr[got] = v ? 1 : 0;
         }
         fclose(fp);
+        if (got != fr.size()) {
+            last_status = WA_ERR_FORMAT;
+            std::cout << "[Grid Map] Truncated grid file: " << got << " of " << fr.size() << " voxels, skipping..." << std::endl;
+            return;
+        }
         wa_ctx *ctx = weldacs_dropin::context();
-        if (!ctx) return;
-        int rc = wa_grid_from_occupancy(ctx, fr.data(), rx, ry, rz, cx.data(), cy.data(), cz.data(), precision, wall, &grid_h);
-        if (rc != WA_OK) { printf("[Grid Map] %s\n", wa_last_error(ctx)); return; }
+        if (!ctx) { last_status = WA_ERR_DEVICE; return; }
+        last_status = wa_grid_from_occupancy(ctx, fr.data(), rx, ry, rz, cx.data(), cy.data(), cz.data(), precision, wall, &grid_h);
+        if (last_status != WA_OK) { printf("[Grid Map] %s\n", wa_last_error(ctx)); return; }
         materialise();
         printf("\n[Grid Map] Successfully read grid map from %s \r\n", file_name.c_str());
     }
@@ -152,6 +175,12 @@ public:
 
     // extension: the opaque device grid behind this map
     wa_grid *device_grid() const { return grid_h; }
+    // extension: status of the last creatGridMap / readGridMap (wa_status)
+    int gridStatus() const { return last_status; }
+    // extension: grid-file format.  Default: the TRUE bounding box with 9 significant digits, so that readGridMap
+    // rebuilds exactly the grid that was written.  Compat: byte for byte the reference's file (model_grid_map.hpp:275-294)
+    // -- "%f" and the last triangle's box instead of the mesh's, which does not round-trip.
+    void setGridFileCompat(bool on) { file_compat = on; }
 
     T precision;
     int wall;
@@ -170,7 +199,10 @@ private:
     std::vector<Vertex3<float> **> planes;
     wa_grid *grid_h = NULL;
     T min_x = 0, min_y = 0, min_z = 0, max_x = 0, max_y = 0, max_z = 0;
+    T q5_lo[3] = {0, 0, 0}, q5_hi[3] = {0, 0, 0};
     int map_size = 0;
+    int last_status = WA_OK;
+    bool file_compat = false;
 
     void release()
     {
@@ -214,9 +246,14 @@ private:
     void write_file(const std::string &file_name)
     {
         FILE *fp = fopen(file_name.c_str(), "w");
-        if (!fp) return;
-        fprintf(fp, "%d %d %d %d %.9g %d\n", map_size, rangeX, rangeY, rangeZ, (double)precision, wall);
-        fprintf(fp, "%.9g %.9g %.9g %.9g %.9g %.9g\n", (double)min_x, (double)min_y, (double)min_z, (double)max_x, (double)max_y, (double)max_z);
+        if (!fp) { last_status = WA_ERR_FILE; return; }
+        if (file_compat) {
+            fprintf(fp, "%d %d %d %d %f %d\n", map_size, rangeX, rangeY, rangeZ, precision, wall);
+            fprintf(fp, "%f %f %f %f %f %f\n", q5_lo[0], q5_lo[1], q5_lo[2], q5_hi[0], q5_hi[1], q5_hi[2]);
+        } else {
+            fprintf(fp, "%d %d %d %d %.9g %d\n", map_size, rangeX, rangeY, rangeZ, (double)precision, wall);
+            fprintf(fp, "%.9g %.9g %.9g %.9g %.9g %.9g\n", (double)min_x, (double)min_y, (double)min_z, (double)max_x, (double)max_y, (double)max_z);
+        }
         for (int i = 0; i < rangeZ; i++)
             for (int j = 0; j < rangeY; j++) {
                 for (int k = 0; k < rangeX; k++) fprintf(fp, "%d ", (int)grid_map[i][j][k].isFree);
