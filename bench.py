@@ -252,11 +252,15 @@ def main():
         achieved = r128["achieved"]
         # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot host rocprofv3
         # itself): only quoted when that file is about THIS kernel at THIS size
-        traffic, traffic_src = None, None
+        traffic, traffic_256, traffic_src = None, None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["kernel"] == "k_evaporate" and pt["grid"] == n:
-                traffic = float(pt["fetch_bytes_corrected"] + pt["write_bytes"])
+            if pt["kernel"] == "k_evaporate":
+                g = pt["grids"]
+                if str(n) in g:
+                    traffic = float(g[str(n)]["fetch_bytes_corrected"] + g[str(n)]["write_bytes"])
+                if "256" in g and r256:
+                    traffic_256 = float(g["256"]["fetch_bytes_corrected"] + g["256"]["write_bytes"])
                 traffic_src = pt["source"]
         except (OSError, KeyError, ValueError):
             pass
@@ -276,7 +280,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": r128["avg_launch_ms"], "sampled_launches": r128["launches"],
                          "note": "two 48 MiB buffers fit the 256 MiB Infinity Cache at this size; frac_256 is the past-the-cache figure",
-                         "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None,
+                         "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None, "traffic_256": traffic_256,
                          "sweep_256": r256,
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
             "fused_launch": {"kernel": "k_evap_rank_mark (sweep + rank + deposit marks of one generation in one launch)",

@@ -28,6 +28,12 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert rf["algorithmic_bytes_per_launch"] == 48.0 * 128 ** 3
+    # the roofline figure comes from the sweep kernel launched alone (>= 64 stamped launches whatever --steps is), at the
+    # BASELINE size and past the Infinity Cache; measured traffic (committed PMC passes) is within 2 % of the algorithmic bytes
+    assert rf["sampled_launches"] >= 64 and rf["kernel"].startswith("k_evaporate")
+    assert 0.3 < rf["frac_256"] < 1.0 and rf["sweep_256"]["algorithmic_bytes_per_launch"] == 48.0 * 256 ** 3
+    assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.02 and abs(rf["traffic_256"] / (48.0 * 256 ** 3) - 1.0) < 0.02
+    assert d["fused_launch"]["sampled_launches"] >= 32 and d["fused_launch"]["avg_launch_ms"] > rf["avg_launch_ms"] * 0.9
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["cost_check"]["bit_equal_trace"] is True  # the GPU's best-cost history equals the CPU port's

@@ -150,20 +150,6 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 
-// L as a function of the step count: Agent::addNextNode adds `distance` (== precision for face moves, :378) once per
-// step (:78), sequentially in fp32 -- not i * precision.  One wavefront runs the chain, lane l keeps entry 64c + l.
-__global__ __launch_bounds__(64) void k_ltab(float *ltab, int32_t count, float precision)
-{
-    float L = 0.f, mine = 0.f;
-    for (int32_t base = 0; base < count; base += 64) {
-        for (int q = 0; q < 64; q++) {
-            if ((int)threadIdx.x == q) mine = L;
-            L += precision;
-        }
-        if (base + (int32_t)threadIdx.x < count) ltab[base + threadIdx.x] = mine;
-    }
-}
-
 #define WA_LAZY_PERIOD 16
 // stored value -> value after `lag` more evaporations (:270, one rounding per multiplication like the sweep)
 __device__ __forceinline__ float wa_catch_up(float v, uint32_t lag, float rho)
