@@ -141,6 +141,7 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.clean[0] = c.clean[c.gen & 1];   // lazy evaporation: the field's clean value carries over; generation parity restarts
     c.evap_base += (uint32_t)c.gen;    // ... and so does the count of evaporations applied so far
     c.gen = 0;
+    c.tabu_gen = -2;
     c.bestL = INFINITY;  // :232; the best PATH is kept (Q9) but unreachable while bestL is inf
     c.best_len = 0;
     c.n_dep = 0;
@@ -957,8 +958,13 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     const int32_t k2 = threadIdx.x & 15;
     const int32_t kk = k2 < 6 ? k2 : 5;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
-    const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
+    uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+    // the best path changed in the generation just ranked: its prefix-tabu bits (which neighbours of best[i] lie on
+    // best[0..i]) are rebuilt here, one row per node and all rows at once, instead of by the single block that ranks --
+    // that block's dependent gathers used to outlast the whole evaporation sweep in exploratory generations
+    const bool rebuild = ctl->tabu_gen + 1 == ctl->gen;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
@@ -984,10 +990,17 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
             p = stv == 0 ? copysignf(clean_now, p) : copysignf(wa_catch_up(fabsf(p), evap_tab + 1u - stv, R.rho), p);
         }
         unsigned long long m = apply_here ? mask[e] : 0ULL;
-        const uint32_t bt = btabu[i];
         int32_t nbid = v + dk;
-        nbid = nbid < 0 ? 0 : nbid > last_id ? last_id : nbid;       // (only consulted when the edge was walked: in bounds then)
-        const uint32_t mk = apply_here ? mark[nbid] : 0u;
+        nbid = nbid < 0 ? 0 : nbid > last_id ? last_id : nbid;       // (an out-of-bounds edge is inadmissible by its sign bit whatever is found here)
+        const uint32_t mk = (apply_here || rebuild) ? mark[nbid] : 0u;
+        uint32_t bt;
+        if (rebuild) {   // neighbour k2 is tabu for an ant standing on best[i] that came along the path iff it lies on best[0..i]
+            const bool on = k2 < 6 && mk == ver && pos[nbid] <= i;
+            bt = (uint32_t)(__ballot(on) >> (threadIdx.x & 48)) & 0x3fu;   // the six lanes of this 16-lane row
+            if (k2 == 0) btabu[i] = (uint8_t)bt;
+        } else {
+            bt = btabu[i];
+        }
         bool adm = false;
         if (k2 < 6) {
             if (m) {  // somebody walked (v, k2): apply the ranked deposits in ascending rank order (:210-211)
@@ -1208,34 +1221,6 @@ __device__ inline void wa_std_sort(WaRec *v, int32_t n)
     } else ss_insertion_sort(v, v + n);
 }
 
-// After the best path was re-stamped (mark/pos) by THIS block: for every node i, which of its six
-// neighbours already lie on the prefix best[0..i].  Static per best path, so it is computed here --
-// a few times per run -- instead of two dependent gathers per node in every generation's
-// k_replay_table.
-__device__ __forceinline__ void wa_best_prefix_tabu(const WaAcsDev &D, int32_t slot, int32_t blen, uint32_t ver)
-{
-    __syncthreads();  // the block's own mark/pos stores are visible to all of its threads
-    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
-    const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
-    const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
-    uint8_t *bt = D.besttabu + (int64_t)slot * D.path_cap;
-    for (int32_t i = threadIdx.x; i < blen; i += blockDim.x) {
-        const int32_t v = bpath[i] & (int32_t)WA_ID_MASK;
-        const int32_t x = v % D.d.nx, y = (v / D.d.nx) % D.d.ny, z = v / D.d.nxy;
-        uint32_t bits = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
-                          Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
-            if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
-                const int32_t nb = v + wa_delta(k, D.d.nx, D.d.nxy);
-                if (mark[nb] == ver && pos[nb] <= i) bits |= 1u << k;
-            }
-        }
-        bt[i] = (uint8_t)bits;
-    }
-}
-
 // ------------------------------------------------------------------ rank
 // one workgroup per problem: iteration best -> global best (strict <, first ant wins :263-264),
 // ranking (:273-275), per-rank deposit coefficient, trace, next generation's parameters.
@@ -1307,9 +1292,8 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
             mark[w & WaNbT<NB>::IDM] = ver;
             pos[w & WaNbT<NB>::IDM] = i;
         }
-        if (NB == 6) wa_best_prefix_tabu(D, slot, blen, ver);   // replay support exists for the 6-neighbour walk only
         bestL = iterL;
-        if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; }
+        if (tid == 0) { ctl->bestL = bestL; ctl->best_len = blen; ctl->best_ver = ver; ctl->tabu_gen = gen; }   // the replay-table rows rebuild the prefix-tabu bits
     }
     // ---- ranking
     if (R.rng_mode == 1) {  // DEV: ascending (L, ant) by counting
@@ -1495,6 +1479,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         float bestL = ctl->bestL;
         uint32_t ver = ctl->best_ver;
         int32_t blen = ctl->best_len;
+        bool changed = false;
         if (iterAnt >= 0 && iterL < bestL) {
             blen = antLen[iterAnt];
             const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
@@ -1508,8 +1493,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
                 mark[w & WA_ID_MASK] = ver;
                 pos[w & WA_ID_MASK] = i;
             }
-            wa_best_prefix_tabu(D, slot, blen, ver);
             bestL = iterL;
+            changed = true;
         }
         if (tid == 0) {
             if (gen < D.trace_cap) {
@@ -1529,6 +1514,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             c.dep_bestL = bestL;
             c.n_dep = n_dep;
             c.gen = gen + 1;
+            if (changed) c.tabu_gen = gen;   // the replay-table rows of this generation rebuild the prefix-tabu bits
             c.clean[(gen + 1) & 1] = c.clean[gen & 1] * R.rho;   // what one more evaporation makes of a never-deposited edge
             wa_next_params(c, R, (gen + 1) & 1);
             *ctl = c;  // nothing a sibling block reads during this launch changes: [gen&1] slots, start/end/stream

@@ -54,7 +54,7 @@ struct WaSlotCtl {
     // evaporations so far, pheromone_0 * rho * rho * ... in the reference's own fp32 rounding; slot [g & 1] like the others
     float clean[2];
     uint32_t evap_base;     // evaporations applied to the field before generation 0 of the current solve (carried across solves)
-    uint32_t pad_;
+    int32_t tabu_gen;       // generation in which the best path last changed: the replay-table rows of that generation rebuild besttabu[]
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index
