@@ -559,10 +559,11 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     "s_branch Lwa_redo_" X "%=\n"
 // no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
 // CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
-#define WA_ASM_RARE(CP, CH, X)                                                                                    \
+#define WA_ASM_RARE(CP, CH, X, IDX)                                                                               \
     "Lwa_rare_" X "%=:\n"                                                                                         \
     "v_mov_b32 %[pio], " CP "\n"                                                                                  \
     "v_mov_b32 %[hio], " CH "\n"                                                                                  \
+    "s_mov_b32 s47, " IDX "\n"                                                                                    \
     "s_cmp_eq_u64 s[54:55], 0\n"                                                                                  \
     "s_cbranch_scc0 Lwa_dead%=\n"                                                                                 \
     "s_branch Lwa_event%=\n"
@@ -608,7 +609,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
     int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on
     for (;;) {
-        // the loop checks its limits once per 64-step block: only enter a block that fits entirely
+        // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
         int32_t code;
         asm volatile(
@@ -641,15 +642,53 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
             "s_branch Lwa_top%=\n"
             WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-            WA_ASM_RARE("v71", "v72", "a") WA_ASM_RARE("v73", "v74", "b") WA_ASM_RARE("v71", "v72", "c") WA_ASM_RARE("v73", "v74", "d")
+            WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
             "Lwa_dead%=:\n"
             "s_mov_b32 %[code], 1\n"
             "s_branch Lwa_out%=\n"
-            "Lwa_event%=:\n"                               // a complete block takes precedence: the caller flushes it, then tests arrival itself
+            // ---- pending event: the previous step completed a 64-word block and/or arrived
+            "Lwa_event%=:\n"
             "s_mov_b32 %[code], 2\n"
             "s_and_b32 s46, m0, 63\n"
-            "s_cbranch_scc1 Lwa_out%=\n"
+            "s_cbranch_scc1 Lwa_out%=\n"                   // no complete block: it is the arrival (:182-186)
+            "s_lshl_b32 s46, m0, 2\n"                      // block [len-64, len) -> path[]: one coalesced 256-byte store
+            "v_lshlrev_b32 v94, 2, v64\n"
+            "v_add_u32 v94, s46, v94\n"
+            "v_add_u32 v94, 0xffffff00, v94\n"
+            "global_store_dword v94, %[pbuf], %[path]\n"
+            "s_cmp_eq_u32 %[cur], %[end]\n"
+            "s_cbranch_scc1 Lwa_out%=\n"                   // ... and arrived with it (code 2)
             "s_mov_b32 %[code], 0\n"
+            "s_add_i32 s46, m0, 64\n"
+            "s_cmp_gt_i32 s46, %[limit]\n"
+            "s_cbranch_scc1 Lwa_out%=\n"                   // the next block would pass the table-load / capacity limit: the caller's generic loop goes on
+            "v_add_u32 v94, m0, v64\n"                     // the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw)
+            "v_add_u32 v94, -1, v94\n"
+            "s_mov_b32 s46, 0x9e3779b9\n"
+            "v_mul_lo_u32 v94, v94, s46\n"
+            "v_add_u32 v94, %[klo], v94\n"
+            "v_xor_b32 v94, %[khi], v94\n"
+            "v_lshrrev_b32 v95, 16, v94\n"
+            "v_xor_b32 v94, v95, v94\n"
+            "s_mov_b32 s46, 0x7feb352d\n"
+            "v_mul_lo_u32 v94, v94, s46\n"
+            "v_lshrrev_b32 v95, 15, v94\n"
+            "v_xor_b32 v94, v95, v94\n"
+            "s_mov_b32 s46, 0x846ca68b\n"
+            "v_mul_lo_u32 v94, v94, s46\n"
+            "v_lshrrev_b32 v95, 16, v94\n"
+            "v_xor_b32 v94, v95, v94\n"
+            "v_lshrrev_b32 v94, 1, v94\n"
+            "v_cvt_f32_u32 v94, v94\n"
+            "v_mul_f32 %[ub], 0x30000000, v94\n"           // (float)r / 2^31 (:169)
+            "s_lshl_b64 s[54:55], 63, %[g8]\n"             // the active mask back: evaluate the pending step again
+            "s_cmp_eq_u32 s47, 0\n"
+            "s_cbranch_scc1 Lwa_redo_a%=\n"
+            "s_cmp_eq_u32 s47, 1\n"
+            "s_cbranch_scc1 Lwa_redo_b%=\n"
+            "s_cmp_eq_u32 s47, 2\n"
+            "s_cbranch_scc1 Lwa_redo_c%=\n"
+            "s_branch Lwa_redo_d%=\n"
             "Lwa_out%=:\n"
             "s_mov_b32 %[len], m0\n"
 #if defined(WA_ASM_STAMPS)
@@ -658,13 +697,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
 #endif
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-            : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf)
-            : [ub] "v"(ublock), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end)
+            : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
+            : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
+              [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
             : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
               "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "s40", "s41", "s42", "s43",
-              "s44", "s45", "s46", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc",
+              "s44", "s45", "s46", "s47", "s48", "s49", "v94", "v95", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc",
 #if defined(WA_ASM_STAMPS)
-              "v94", "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
+              "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
 #endif
               "m0", "memory");
 #if defined(WA_ASM_STAMPS)
@@ -673,12 +713,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             for (int i = 0; i < 6; i++) atomicAdd(&dbg[i], (unsigned long long)(uint32_t)lcs[(7 + i) * 64]);
         }
 #endif
-        if (code == 0) {   // a block of 64 path words is complete: one coalesced store, next block of draws
-            path[(len - 64) + lane] = pbuf;
-            if (cur == end) { exit_code = 2; break; }
-            ublock = (float)wa_ctr_draw(antkey, (uint32_t)(len + lane - 1)) / 2147483648.0f;
-            continue;
-        }
+        if (code == 0) continue;   // stopped at a block boundary (the block is stored): the limit test above decides
         exit_code = code;
         break;
     }
