@@ -382,6 +382,8 @@ struct wo_acs {
     int32_t *last_len;    /* per-ant node count / L of the last generation walked (agents[] of :251) */
     float *last_L;
     int32_t last_cap;
+    int32_t *last_ids;    /* their paths, back to back (diagnostics) */
+    int64_t last_ids_cap;
 };
 
 static void ant_push(wo_ant *a, int32_t id, int8_t ch)
@@ -450,7 +452,7 @@ void wo_acs_destroy(wo_acs *s)
 {
     if (!s) return;
     free(s->cx); free(s->cy); free(s->cz); free(s->free_); free(s->pher); free(s->visit);
-    free(s->bestmark); free(s->best.ids); free(s->best.choice); free(s->last_len); free(s->last_L); free(s);
+    free(s->bestmark); free(s->best.ids); free(s->best.choice); free(s->last_len); free(s->last_L); free(s->last_ids); free(s);
 }
 
 void wo_acs_reset(wo_acs *s, float pheromone_0)
@@ -638,7 +640,13 @@ int32_t wo_acs_solve(wo_acs *s, const wo_acs_params *p, int64_t start_id, int64_
             s->last_L = (float *)realloc(s->last_L, sizeof(float) * (size_t)colony);
             s->last_cap = colony;
         }
-        for (int32_t a = 0; a < colony; a++) { s->last_len[a] = (int32_t)ants[a].len; s->last_L[a] = ants[a].L; }
+        int64_t tot = 0;
+        for (int32_t a = 0; a < colony; a++) { s->last_len[a] = (int32_t)ants[a].len; s->last_L[a] = ants[a].L; tot += ants[a].len; }
+        if (g == p->max_iteration - 1) {
+            if (tot > s->last_ids_cap) { s->last_ids = (int32_t *)realloc(s->last_ids, sizeof(int32_t) * (size_t)tot); s->last_ids_cap = tot; }
+            int64_t o = 0;
+            for (int32_t a = 0; a < colony; a++) { memcpy(s->last_ids + o, ants[a].ids, sizeof(int32_t) * (size_t)ants[a].len); o += ants[a].len; }
+        }
     }
     for (int32_t a = 0; a < ants_cap; a++) { free(ants[a].ids); free(ants[a].choice); }
     free(ants); free(keys); free(perm);
@@ -657,6 +665,12 @@ const float *wo_acs_pheromone(const wo_acs *s) { return s->pher; }
 void wo_acs_last_params(const wo_acs *s, int32_t *colony, float *lambda, float *Q)
 {
     *colony = s->last_colony; *lambda = s->last_lambda; *Q = s->last_Q;
+}
+void wo_acs_last_paths(const wo_acs *s, int32_t *ids)
+{
+    int64_t tot = 0;
+    for (int32_t a = 0; a < s->last_colony; a++) tot += s->last_len[a];
+    memcpy(ids, s->last_ids, sizeof(int32_t) * (size_t)tot);
 }
 int32_t wo_acs_last_ants(const wo_acs *s, int32_t *lens, float *L)
 {

@@ -56,6 +56,7 @@ struct WaAcsDev {
     int32_t *dcount;               // [slot][2]
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
+    int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
 };
 
 // path word = voxel id | (edge index taken to arrive << SHIFT)
@@ -478,11 +479,45 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
 // other instructions sit between them; a conditional branch costs ~13 cycles not taken, ~23 taken.  Hence: compares
 // early, their scalar consumers late, and ONE rare-event branch per step -- a completed 64-word block and the arrival
 // zero the active-lane mask, so the NEXT step finds no candidate and leaves through the same exit as a dead end.
-#define WA_ASM_STEP(CP, CH, NP, NH, X)                                                                            \
+// dense field: info = |p| * h.  lazy field (wa_acs_create_lazy): the stamp of cur's record decides -- 0: never deposited, every
+// admissible edge is worth the clean value; else the stored value with the evaporations it has missed applied one by one
+#define WA_ASM_INFO_DENSE(CP, CH, CS, X) "v_mul_f32 v78, |" CP "|, " CH "\n"              /* info (:154), alpha == 1 */
+#define WA_ASM_INFO_LAZY(CP, CH, CS, X)                                                                           \
+    "v_readlane_b32 s36, " CS ", %[g8]\n"                         /* stamp of cur: the same in the six lanes of the active block */ \
+    "v_mul_f32 v78, s33, " CH "\n"                                /* clean value x heuristic (the common case in pair planning) */
+#define WA_ASM_INFO2_DENSE(X) ""
+#define WA_ASM_INFO2_LAZY(X)                                                                                      \
+    "s_cmp_eq_u32 s36, 0\n"                                                                                       \
+    "s_cbranch_scc0 Lwa_dirty_" X "%=\n"                                                                          \
+    "Lwa_info_" X "%=:\n"
+#define WA_ASM_HEAD_DENSE(NS) ""
+#define WA_ASM_HEAD_LAZY(NS)                                                                                      \
+    "s_lshl_b32 s46, %[cur], 2\n"                                                                                 \
+    "v_add_u32 v98, s46, v99\n"                                                                                   \
+    "global_load_dword " NS ", v98, %[stamp]\n"                   /* the neighbour's stamp travels with its record */
+// a deposited record: stored value -> value after the evaporations it missed (one rounding per multiplication, like the sweep)
+#define WA_ASM_DIRTY(CP, CH, X)                                                                                   \
+    "Lwa_dirty_" X "%=:\n"                                                                                        \
+    "s_sub_u32 s37, s34, s36\n"                                   /* evap_now + 1 - stamp */                      \
+    "v_and_b32 v78, 0x7fffffff, " CP "\n"                                                                         \
+    "s_cmp_eq_u32 s37, 0\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_dirty2_" X "%=\n"                                                                         \
+    "Lwa_catch_" X "%=:\n"                                                                                        \
+    "v_mul_f32 v78, s35, v78\n"                                                                                   \
+    "s_sub_u32 s37, s37, 1\n"                                                                                     \
+    "s_cmp_lg_u32 s37, 0\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_catch_" X "%=\n"                                                                          \
+    "Lwa_dirty2_" X "%=:\n"                                                                                       \
+    "v_mul_f32 v78, v78, " CH "\n"                                                                                \
+    "s_branch Lwa_info_" X "%=\n"
+#define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT)
+#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n")
+#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT)                                       \
     "s_mul_i32 s40, %[cur], 24\n"                                                                                 \
     "v_add_u32 v82, s40, v65\n"                                                                                   \
     "global_load_dword " NP ", v82, %[pher]\n"                    /* records of the six neighbours: needed next step */ \
     "global_load_dword " NH ", v82, %[heur]\n"                                                                    \
+    HEAD(NS)                                                                                                      \
     WA_ASM_WARM_ADDR                                                                                              \
     "Lwa_redo_" X "%=:\n"                                                                                         \
     WA_ASM_STAMP(72)                                                                                              \
@@ -490,12 +525,13 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     WA_ASM_STAMP(73)                                                                                              \
     "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
     "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
-    WA_ASM_VMWAIT                                                 /* records of cur; the touch loads + the 2 new ones stay in flight */ \
+    VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
     WA_ASM_STAMP(74)                                                                                              \
     "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
-    "v_mul_f32 v78, |" CP "|, " CH "\n"                           /* info (:154), alpha == 1 */                   \
+    INFO(CP, CH, CS, X)                                                                                           \
     WA_ASM_WARM0                                                  /* records two hops away: touched, never waited for */ \
     WA_ASM_WARM1                                                                                                  \
+    INFO2(X)                                                                                                      \
     "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
     "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
     "s_and_b64 s[50:51], s[50:51], vcc\n"                         /* ... and not visited (:145) */                \
@@ -559,19 +595,112 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     "s_branch Lwa_redo_" X "%=\n"
 // no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
 // CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
-#define WA_ASM_RARE(CP, CH, X, IDX)                                                                               \
-    "Lwa_rare_" X "%=:\n"                                                                                         \
+#define WA_ASM_RARE_BODY(CP, CH, IDX)                                                                             \
     "v_mov_b32 %[pio], " CP "\n"                                                                                  \
     "v_mov_b32 %[hio], " CH "\n"                                                                                  \
     "s_mov_b32 s47, " IDX "\n"                                                                                    \
     "s_cmp_eq_u64 s[54:55], 0\n"                                                                                  \
     "s_cbranch_scc0 Lwa_dead%=\n"                                                                                 \
     "s_branch Lwa_event%=\n"
+#define WA_ASM_RARE(CP, CH, X, IDX) "Lwa_rare_" X "%=:\n" WA_ASM_RARE_BODY(CP, CH, IDX)
 
+// the pieces of the loop's assembly text that the dense and the lazy variant share
+#define WA_ASM_PROLOGUE                                                                                           \
+    "ds_read_b32 v64, %[lc]\n"                                                                                    \
+    "ds_read_b32 v65, %[lc] offset:256\n"                                                                         \
+    "ds_read_b32 v66, %[lc] offset:512\n"                                                                         \
+    "ds_read_b32 v67, %[lc] offset:768\n"                                                                         \
+    "ds_read_b32 v68, %[lc] offset:1024\n"                                                                        \
+    "ds_read_b32 v69, %[lc] offset:1280\n"                                                                        \
+    "ds_read_b32 v70, %[lc] offset:1536\n"                                                                        \
+    "v_mov_b32 v71, %[pio]\n"                                                                                     \
+    "v_mov_b32 v72, %[hio]\n"                                                                                     \
+    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
+    "s_mov_b32 m0, %[len]\n"                      /* the node count lives in m0: lane select of the draw and of the path word */ \
+    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "v_add_u32 v77, s41, v67\n"                                                                                   \
+    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
+    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
+    "ds_read_b32 v75, v77\n"                                                                                      \
+    "v_add_u32 v76, %[cur], v68\n"
+#if defined(WA_ASM_STAMPS)
+#define WA_ASM_STAMPS_INIT "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n" \
+                           "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
+#define WA_ASM_STAMPS_DUMP "v_mov_b32 v94, s72\n ds_write_b32 %[lc], v94 offset:1792\n v_mov_b32 v94, s73\n ds_write_b32 %[lc], v94 offset:2048\n" \
+                           "v_mov_b32 v94, s74\n ds_write_b32 %[lc], v94 offset:2304\n v_mov_b32 v94, s75\n ds_write_b32 %[lc], v94 offset:2560\n" \
+                           "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
+#define WA_ASM_STAMPS_CLOBBER "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
+#else
+#define WA_ASM_STAMPS_INIT ""
+#define WA_ASM_STAMPS_DUMP ""
+#define WA_ASM_STAMPS_CLOBBER
+#endif
+// everything behind the loop: the dead-end exit and the pending-event handler (a completed 64-word block and/or the arrival)
+#define WA_ASM_TAIL                                                                                               \
+    "Lwa_dead%=:\n"                                                                                               \
+    "s_mov_b32 %[code], 1\n"                                                                                      \
+    "s_branch Lwa_out%=\n"                                                                                        \
+    "Lwa_event%=:\n"                                                                                              \
+    "s_mov_b32 %[code], 2\n"                                                                                      \
+    "s_and_b32 s46, m0, 63\n"                                                                                     \
+    "s_cbranch_scc1 Lwa_out%=\n"                   /* no complete block: it is the arrival (:182-186) */          \
+    "s_lshl_b32 s46, m0, 2\n"                      /* block [len-64, len) -> path[]: one coalesced 256-byte store */ \
+    "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
+    "v_add_u32 v94, s46, v94\n"                                                                                   \
+    "v_add_u32 v94, 0xffffff00, v94\n"                                                                            \
+    "global_store_dword v94, %[pbuf], %[path]\n"                                                                  \
+    "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
+    "s_cbranch_scc1 Lwa_out%=\n"                   /* ... and arrived with it (code 2) */                         \
+    "s_mov_b32 %[code], 0\n"                                                                                      \
+    "s_add_i32 s46, m0, 64\n"                                                                                     \
+    "s_cmp_gt_i32 s46, %[limit]\n"                                                                                \
+    "s_cbranch_scc1 Lwa_out%=\n"                   /* the next block would pass the table-load / capacity limit: the caller's generic loop goes on */ \
+    "v_add_u32 v94, m0, v64\n"                     /* the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw) */ \
+    "v_add_u32 v94, -1, v94\n"                                                                                    \
+    "s_mov_b32 s46, 0x9e3779b9\n"                                                                                 \
+    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
+    "v_add_u32 v94, %[klo], v94\n"                                                                                \
+    "v_xor_b32 v94, %[khi], v94\n"                                                                                \
+    "v_lshrrev_b32 v95, 16, v94\n"                                                                                \
+    "v_xor_b32 v94, v95, v94\n"                                                                                   \
+    "s_mov_b32 s46, 0x7feb352d\n"                                                                                 \
+    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
+    "v_lshrrev_b32 v95, 15, v94\n"                                                                                \
+    "v_xor_b32 v94, v95, v94\n"                                                                                   \
+    "s_mov_b32 s46, 0x846ca68b\n"                                                                                 \
+    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
+    "v_lshrrev_b32 v95, 16, v94\n"                                                                                \
+    "v_xor_b32 v94, v95, v94\n"                                                                                   \
+    "v_lshrrev_b32 v94, 1, v94\n"                                                                                 \
+    "v_cvt_f32_u32 v94, v94\n"                                                                                    \
+    "v_mul_f32 %[ub], 0x30000000, v94\n"           /* (float)r / 2^31 (:169) */                                   \
+    "s_lshl_b64 s[54:55], 63, %[g8]\n"             /* the active mask back: evaluate the pending step again */    \
+    "s_cmp_eq_u32 s47, 0\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_redo_a%=\n"                                                                               \
+    "s_cmp_eq_u32 s47, 1\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_redo_b%=\n"                                                                               \
+    "s_cmp_eq_u32 s47, 2\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_redo_c%=\n"                                                                               \
+    "s_branch Lwa_redo_d%=\n"                                                                                     \
+    "Lwa_out%=:\n"                                                                                                \
+    "s_mov_b32 %[len], m0\n"                                                                                      \
+    WA_ASM_STAMPS_DUMP                                                                                            \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#define WA_ASM_CLOBBERS                                                                                           \
+    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82",  \
+        "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44",     \
+        "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
+        "vcc", "scc", "m0", "memory"
+
+// LAZY: the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the slot's stamp array,
+// clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far
+template <bool LAZY>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
+                                                 const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
                                                  int32_t *__restrict__ path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
                                                  int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
-                                                 int32_t guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
+                                                 int32_t guard_bytes, int32_t stamp_guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
                                                  int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg)
 {
     const int lane = threadIdx.x;
@@ -585,6 +714,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     // field bases moved back by the guard band: every offset the loop forms is then non-negative
     const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
     const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
+    const char *stamp_b = LAZY ? reinterpret_cast<const char *>(stamp) - stamp_guard_bytes : nullptr;
     {   // lane constants (columns of 64 dwords behind the dummy slots)
         int32_t *lc = tab + table + 64;
         lc[0 * 64 + lane] = lane;
@@ -594,6 +724,10 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         lc[4 * 64 + lane] = dk;
         lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
         lc[6 * 64 + lane] = (table + lane) * 4;                                      // this lane's dummy slot
+        if (LAZY) {
+            lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
+            lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : __float_as_int(R.rho);
+        }
     }
     const int32_t lcaddr = (table + 64 + lane) * 4;
     int32_t cur = st.cur, len = st.len, g8 = 0;
@@ -606,107 +740,59 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         p = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pher) + boff);
         h = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(heur) + boff);
     }
+    uint32_t pd = LAZY ? stamp[cur] : 1u;
     const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
     int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on
     for (;;) {
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
         int32_t code;
-        asm volatile(
-            "ds_read_b32 v64, %[lc]\n"
-            "ds_read_b32 v65, %[lc] offset:256\n"
-            "ds_read_b32 v66, %[lc] offset:512\n"
-            "ds_read_b32 v67, %[lc] offset:768\n"
-            "ds_read_b32 v68, %[lc] offset:1024\n"
-            "ds_read_b32 v69, %[lc] offset:1280\n"
-            "ds_read_b32 v70, %[lc] offset:1536\n"
-            "v_mov_b32 v71, %[pio]\n"
-            "v_mov_b32 v72, %[hio]\n"
-            "s_lshl_b64 s[54:55], 63, %[g8]\n"
-            "s_mov_b32 m0, %[len]\n"                      // the node count lives in m0: lane select of the draw and of the path word
-            "s_mul_i32 s41, %[cur], 0x9e3779b1\n"
-            "s_waitcnt lgkmcnt(0)\n"
-            "v_add_u32 v77, s41, v67\n"
-            "v_lshrrev_b32 v77, %[hs], v77\n"
-            "v_lshlrev_b32 v77, 2, v77\n"
-            "ds_read_b32 v75, v77\n"
-            "v_add_u32 v76, %[cur], v68\n"
-#if defined(WA_ASM_STAMPS)
-            "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n"
-            "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
-#endif
-            "Lwa_top%=:\n"
-            WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
-            WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
-            WA_ASM_STEP("v71", "v72", "v73", "v74", "c")
-            WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
-            "s_branch Lwa_top%=\n"
-            WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-            WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
-            "Lwa_dead%=:\n"
-            "s_mov_b32 %[code], 1\n"
-            "s_branch Lwa_out%=\n"
-            // ---- pending event: the previous step completed a 64-word block and/or arrived
-            "Lwa_event%=:\n"
-            "s_mov_b32 %[code], 2\n"
-            "s_and_b32 s46, m0, 63\n"
-            "s_cbranch_scc1 Lwa_out%=\n"                   // no complete block: it is the arrival (:182-186)
-            "s_lshl_b32 s46, m0, 2\n"                      // block [len-64, len) -> path[]: one coalesced 256-byte store
-            "v_lshlrev_b32 v94, 2, v64\n"
-            "v_add_u32 v94, s46, v94\n"
-            "v_add_u32 v94, 0xffffff00, v94\n"
-            "global_store_dword v94, %[pbuf], %[path]\n"
-            "s_cmp_eq_u32 %[cur], %[end]\n"
-            "s_cbranch_scc1 Lwa_out%=\n"                   // ... and arrived with it (code 2)
-            "s_mov_b32 %[code], 0\n"
-            "s_add_i32 s46, m0, 64\n"
-            "s_cmp_gt_i32 s46, %[limit]\n"
-            "s_cbranch_scc1 Lwa_out%=\n"                   // the next block would pass the table-load / capacity limit: the caller's generic loop goes on
-            "v_add_u32 v94, m0, v64\n"                     // the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw)
-            "v_add_u32 v94, -1, v94\n"
-            "s_mov_b32 s46, 0x9e3779b9\n"
-            "v_mul_lo_u32 v94, v94, s46\n"
-            "v_add_u32 v94, %[klo], v94\n"
-            "v_xor_b32 v94, %[khi], v94\n"
-            "v_lshrrev_b32 v95, 16, v94\n"
-            "v_xor_b32 v94, v95, v94\n"
-            "s_mov_b32 s46, 0x7feb352d\n"
-            "v_mul_lo_u32 v94, v94, s46\n"
-            "v_lshrrev_b32 v95, 15, v94\n"
-            "v_xor_b32 v94, v95, v94\n"
-            "s_mov_b32 s46, 0x846ca68b\n"
-            "v_mul_lo_u32 v94, v94, s46\n"
-            "v_lshrrev_b32 v95, 16, v94\n"
-            "v_xor_b32 v94, v95, v94\n"
-            "v_lshrrev_b32 v94, 1, v94\n"
-            "v_cvt_f32_u32 v94, v94\n"
-            "v_mul_f32 %[ub], 0x30000000, v94\n"           // (float)r / 2^31 (:169)
-            "s_lshl_b64 s[54:55], 63, %[g8]\n"             // the active mask back: evaluate the pending step again
-            "s_cmp_eq_u32 s47, 0\n"
-            "s_cbranch_scc1 Lwa_redo_a%=\n"
-            "s_cmp_eq_u32 s47, 1\n"
-            "s_cbranch_scc1 Lwa_redo_b%=\n"
-            "s_cmp_eq_u32 s47, 2\n"
-            "s_cbranch_scc1 Lwa_redo_c%=\n"
-            "s_branch Lwa_redo_d%=\n"
-            "Lwa_out%=:\n"
-            "s_mov_b32 %[len], m0\n"
-#if defined(WA_ASM_STAMPS)
-            "v_mov_b32 v94, s72\n ds_write_b32 %[lc], v94 offset:1792\n v_mov_b32 v94, s73\n ds_write_b32 %[lc], v94 offset:2048\n"
-            "v_mov_b32 v94, s74\n ds_write_b32 %[lc], v94 offset:2304\n v_mov_b32 v94, s75\n ds_write_b32 %[lc], v94 offset:2560\n"
-            "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
-#endif
-            "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-            : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
-            : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-              [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
-            : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
-              "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "s40", "s41", "s42", "s43",
-              "s44", "s45", "s46", "s47", "s48", "s49", "v94", "v95", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "vcc", "scc",
-#if defined(WA_ASM_STAMPS)
-              "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
-#endif
-              "m0", "memory");
+        if (!LAZY) {
+            asm volatile(
+                WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT
+                "Lwa_top%=:\n"
+                WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
+                WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
+                WA_ASM_STEP("v71", "v72", "v73", "v74", "c")
+                WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
+                "s_branch Lwa_top%=\n"
+                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
+                WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
+                WA_ASM_TAIL
+                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
+                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
+                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
+                : WA_ASM_CLOBBERS);
+        } else {
+            asm volatile(
+                WA_ASM_PROLOGUE
+                "ds_read_b32 v99, %[lc] offset:3328\n"        // stamp offset of this lane's neighbour
+                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 0..2: clean value, evap_now + 1, rho
+                "v_mov_b32 v96, %[sio]\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                "v_readlane_b32 s33, v94, 0\n"
+                "v_readlane_b32 s34, v94, 1\n"
+                "v_readlane_b32 s35, v94, 2\n"
+                WA_ASM_STAMPS_INIT
+                "Lwa_top%=:\n"
+                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "a")
+                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "b")
+                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "c")
+                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "d")
+                "s_branch Lwa_top%=\n"
+                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
+                WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d")
+                "Lwa_rare_a%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "0")
+                "Lwa_rare_b%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "1")
+                "Lwa_rare_c%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "2")
+                "Lwa_rare_d%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "3")
+                WA_ASM_TAIL
+                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock),
+                  [sio] "+v"(pd)
+                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
+                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b)
+                : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", WA_ASM_CLOBBERS);
+        }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {
             const int32_t *lcs = tab + table + 64;
@@ -947,11 +1033,11 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
     bool use_asm = false;
 #ifndef WA_STAMPS
-    use_asm = MODE == 1 && ALPHA1 && !SPARSE && (walk_flags & 1);
+    use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
 #endif
     if (st.len < fast_limit && use_asm)
-        wa_walk_fast_asm(R, pher, heur, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at, D.guard_bytes, D.ltab, st,
-                         flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
+        wa_walk_fast_asm<SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+                                 D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);

@@ -55,6 +55,7 @@ struct wa_acs {
     WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     float *pher_alloc[2], *heur_alloc;   // the allocations behind pher_buf[] / D.heur (fields + guard bands)
+    uint32_t *stamp_alloc;               // ... and D.stamp (lazy solvers)
     int cur_buf;
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
