@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libweldacs.so")
 SOURCES = ["weldacs.hip"]
-DEPS = ["wa_device.h", "acs_kernels.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp", "traj_kernels.hpp",
+DEPS = ["wa_device.h", "acs_kernels.hpp", "walk_loop_gfx950.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp", "traj_kernels.hpp",
         "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
 

@@ -435,389 +435,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
 }
 
-// ------------------------------------------------------------------ the hand-scheduled walk loop
-// DEV mode, alpha == 1, dense field.  Same arithmetic, same operands, same order as wa_walk_fast (the tests hold the
-// two against each other and against the oracle); what changes is what a LONE wavefront pays for: it issues one
-// instruction per ~4 cycles whatever the type, so a step costs (instructions x 4 cycles) + whatever memory latency is
-// left exposed.  The compiler's loop is ~85 instructions and waits for vmcnt(0) at its back edge; this one is ~60 and
-// keeps three generations of loads in flight with exact vmcnt counts:
-//   * records of the six neighbours (needed NEXT step) are requested first, then the records TWO hops away are touched
-//     with two 16-byte loads nobody waits for: by the time they are requested for real they sit in L2 (vector memory
-//     returns in order, so the younger touch loads never hold back the older record loads);
-//   * lanes are laid out so that the roulette's first hit (scanning edge 5 down to 0) is the LOWEST set bit: role k
-//     sits at position 5-k of its 8-lane block, `total` lands in position 0, one s_ff1 picks; block b holds the
-//     record of neighbour 5-b, so the next active block is the picked lane's position;
-//   * no address clamp (guard bands around the fields), no per-step L (table lookup at the end), the path word and the
-//     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
-//     dummy slot), limits are checked per 64-step block instead of per step.
-// Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
-#define WA_WALK_LDS_EXTRA 4096   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants (+ 6 x 64 diagnostic sums)
-#define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
-#define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
-// experiment switches (timing studies only; the product build defines none of them)
-#if defined(WA_ASM_NOWARM)
-#define WA_ASM_WARM_ADDR ""
-#define WA_ASM_WARM0 "s_nop 0\n"
-#define WA_ASM_WARM1 "s_nop 0\n"
-#define WA_ASM_VMWAIT "s_waitcnt vmcnt(2)\n"
-#else
-#define WA_ASM_WARM_ADDR "v_add_u32 v83, s40, v66\n"
-#define WA_ASM_WARM0 "global_load_dwordx4 v[86:89], v83, %[pher]\n"
-#define WA_ASM_WARM1 "global_load_dwordx4 v[90:93], v83, %[heur]\n"
-#define WA_ASM_VMWAIT "s_waitcnt vmcnt(4)\n"
-#endif
-// -DWA_ASM_STAMPS (diagnostic builds, tools/walk_stamps_asm.py): s_memtime at six points of the step, differences summed in
-// s72..s77 (s70 = previous stamp); each stamp drains LDS and costs ~40 cycles: read the shares, not the totals
-#if defined(WA_ASM_STAMPS)
-#define WA_ASM_STAMP(i) "s_memtime s[60:61]\n" "s_waitcnt lgkmcnt(0)\n" "s_sub_u32 s62, s60, s70\n" "s_add_u32 s" #i ", s" #i ", s62\n" "s_mov_b32 s70, s60\n"
-#else
-#define WA_ASM_STAMP(i) ""
-#endif
-// One step.  CP/CH = records of `cur` (arrived or arriving), NP/NH = where the neighbours' records go, X = label suffix.
-// Schedule rules (measured with tools/ubench/issue_rates.hip, one wave alone on its SIMD): every instruction costs
-// ~4.3 cycles; an SALU instruction reading an SGPR/VCC that a VALU instruction wrote stalls ~16 cycles unless four
-// other instructions sit between them; a conditional branch costs ~13 cycles not taken, ~23 taken.  Hence: compares
-// early, their scalar consumers late, and ONE rare-event branch per step -- a completed 64-word block and the arrival
-// zero the active-lane mask, so the NEXT step finds no candidate and leaves through the same exit as a dead end.
-// dense field: info = |p| * h.  lazy field (wa_acs_create_lazy): the stamp of cur's record decides -- 0: never deposited, every
-// admissible edge is worth the clean value; else the stored value with the evaporations it has missed applied one by one
-#define WA_ASM_INFO_DENSE(CP, CH, CS, X) "v_mul_f32 v78, |" CP "|, " CH "\n"              /* info (:154), alpha == 1 */
-#define WA_ASM_INFO_LAZY(CP, CH, CS, X)                                                                           \
-    "v_readlane_b32 s36, " CS ", %[g8]\n"                         /* stamp of cur: the same in the six lanes of the active block */ \
-    "v_mul_f32 v78, s33, " CH "\n"                                /* clean value x heuristic (the common case in pair planning) */
-#define WA_ASM_INFO2_DENSE(X) ""
-#define WA_ASM_INFO2_LAZY(X)                                                                                      \
-    "s_cmp_eq_u32 s36, 0\n"                                                                                       \
-    "s_cbranch_scc0 Lwa_dirty_" X "%=\n"                                                                          \
-    "Lwa_info_" X "%=:\n"
-#define WA_ASM_HEAD_DENSE(NS) ""
-#define WA_ASM_HEAD_LAZY(NS)                                                                                      \
-    "s_lshl_b32 s46, %[cur], 2\n"                                                                                 \
-    "v_add_u32 v98, s46, v99\n"                                                                                   \
-    "global_load_dword " NS ", v98, %[stamp]\n"                   /* the neighbour's stamp travels with its record */
-// a deposited record: stored value -> value after the evaporations it missed (one rounding per multiplication, like the sweep)
-#define WA_ASM_DIRTY(CP, CH, X)                                                                                   \
-    "Lwa_dirty_" X "%=:\n"                                                                                        \
-    "s_sub_u32 s37, s34, s36\n"                                   /* evap_now + 1 - stamp */                      \
-    "v_and_b32 v78, 0x7fffffff, " CP "\n"                                                                         \
-    "s_cmp_eq_u32 s37, 0\n"                                                                                       \
-    "s_cbranch_scc1 Lwa_dirty2_" X "%=\n"                                                                         \
-    "Lwa_catch_" X "%=:\n"                                                                                        \
-    "v_mul_f32 v78, s35, v78\n"                                                                                   \
-    "s_sub_u32 s37, s37, 1\n"                                                                                     \
-    "s_cmp_lg_u32 s37, 0\n"                                                                                       \
-    "s_cbranch_scc1 Lwa_catch_" X "%=\n"                                                                          \
-    "Lwa_dirty2_" X "%=:\n"                                                                                       \
-    "v_mul_f32 v78, v78, " CH "\n"                                                                                \
-    "s_branch Lwa_info_" X "%=\n"
-#define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT)
-#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n")
-#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT)                                       \
-    "s_mul_i32 s40, %[cur], 24\n"                                                                                 \
-    "v_add_u32 v82, s40, v65\n"                                                                                   \
-    "global_load_dword " NP ", v82, %[pher]\n"                    /* records of the six neighbours: needed next step */ \
-    "global_load_dword " NH ", v82, %[heur]\n"                                                                    \
-    HEAD(NS)                                                                                                      \
-    WA_ASM_WARM_ADDR                                                                                              \
-    "Lwa_redo_" X "%=:\n"                                                                                         \
-    WA_ASM_STAMP(72)                                                                                              \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    WA_ASM_STAMP(73)                                                                                              \
-    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
-    "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
-    VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
-    WA_ASM_STAMP(74)                                                                                              \
-    "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
-    INFO(CP, CH, CS, X)                                                                                           \
-    WA_ASM_WARM0                                                  /* records two hops away: touched, never waited for */ \
-    WA_ASM_WARM1                                                                                                  \
-    INFO2(X)                                                                                                      \
-    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
-    "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
-    "s_and_b64 s[50:51], s[50:51], vcc\n"                         /* ... and not visited (:145) */                \
-    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active block */                   \
-    "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
-    "v_readlane_b32 s42, %[ub], m0\n"                             /* this step's uniform draw (:169) */           \
-    "v_add_u32 v85, %[cur], v69\n"                                /* candidate path words: (cur + d_k) | k << 29 */ \
-    "v_add_f32_dpp v80, v78, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v78, v78" WA_ASM_DPP_T                                                                    \
-    "s_nop 0\n"                                                                                                   \
-    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
-    "s_nop 0\n"                                                                                                   \
-    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
-    "s_nop 0\n"                                                                                                   \
-    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
-    "s_nop 0\n"                                                                                                   \
-    "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
-    WA_ASM_STAMP(75)                                                                                              \
-    "v_mul_f32 v81, s42, v79\n"                                   /* rnd = u * total (:170), valid in position 0 */ \
-    "s_nop 0\n"                                                                                                   \
-    "v_readlane_b32 s43, v81, %[g8]\n"                                                                            \
-    "s_nop 1\n"                                                                                                   \
-    "v_cmp_le_f32 vcc, s43, v80\n"                                /* prob_sum >= rnd (:178) */                    \
-    "s_and_b64 s[56:57], vcc, s[52:53]\n"                                                                         \
-    "s_cbranch_scc0 Lwa_rare_" X "%=\n"                           /* no candidate (:162), fall-through (:191), or a pending event */ \
-    WA_ASM_STAMP(76)                                                                                              \
-    "s_ff1_i32_b64 s45, s[56:57]\n"                               /* first hit scanning edge 5 -> 0 */            \
-    "v_cmp_eq_u32 vcc, s45, v64\n"                                                                                \
-    "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
-    "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
-    "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
-    "s_lshl_b32 %[g8], s45, 3\n"                                  /* next active block = position of the pick (low 6 bits count) */ \
-    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
-    "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
-    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
-    "v_add_u32 v77, s41, v67\n"                                                                                   \
-    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
-    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
-    "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
-    "v_add_u32 v76, %[cur], v68\n"                                                                                \
-    "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
-    "s_add_i32 m0, m0, 1\n"                                                                                       \
-    "s_and_b32 s46, m0, 63\n"                                                                                     \
-    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* block of 64 path words complete: event */    \
-    "s_cmp_lg_u32 %[cur], %[end]\n"                                                                               \
-    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* arrived (:182): event */                     \
-    WA_ASM_STAMP(77)
-// some lane's probe hit another key: advance those lanes along their chains, then evaluate the step again
-#define WA_ASM_COLL(X)                                                                                            \
-    "Lwa_coll_" X "%=:\n"                                                                                         \
-    "s_mov_b64 s[58:59], exec\n"                                                                                  \
-    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
-    "v_add_u32 v77, 4, v77\n"                                                                                     \
-    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
-    "ds_read_b32 v75, v77\n"                                                                                      \
-    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
-    "s_branch Lwa_redo_" X "%=\n"
-// no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
-// CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
-#define WA_ASM_RARE_BODY(CP, CH, IDX)                                                                             \
-    "v_mov_b32 %[pio], " CP "\n"                                                                                  \
-    "v_mov_b32 %[hio], " CH "\n"                                                                                  \
-    "s_mov_b32 s47, " IDX "\n"                                                                                    \
-    "s_cmp_eq_u64 s[54:55], 0\n"                                                                                  \
-    "s_cbranch_scc0 Lwa_dead%=\n"                                                                                 \
-    "s_branch Lwa_event%=\n"
-#define WA_ASM_RARE(CP, CH, X, IDX) "Lwa_rare_" X "%=:\n" WA_ASM_RARE_BODY(CP, CH, IDX)
-
-// the pieces of the loop's assembly text that the dense and the lazy variant share
-#define WA_ASM_PROLOGUE                                                                                           \
-    "ds_read_b32 v64, %[lc]\n"                                                                                    \
-    "ds_read_b32 v65, %[lc] offset:256\n"                                                                         \
-    "ds_read_b32 v66, %[lc] offset:512\n"                                                                         \
-    "ds_read_b32 v67, %[lc] offset:768\n"                                                                         \
-    "ds_read_b32 v68, %[lc] offset:1024\n"                                                                        \
-    "ds_read_b32 v69, %[lc] offset:1280\n"                                                                        \
-    "ds_read_b32 v70, %[lc] offset:1536\n"                                                                        \
-    "v_mov_b32 v71, %[pio]\n"                                                                                     \
-    "v_mov_b32 v72, %[hio]\n"                                                                                     \
-    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
-    "s_mov_b32 m0, %[len]\n"                      /* the node count lives in m0: lane select of the draw and of the path word */ \
-    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    "v_add_u32 v77, s41, v67\n"                                                                                   \
-    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
-    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
-    "ds_read_b32 v75, v77\n"                                                                                      \
-    "v_add_u32 v76, %[cur], v68\n"
-#if defined(WA_ASM_STAMPS)
-#define WA_ASM_STAMPS_INIT "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n" \
-                           "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
-#define WA_ASM_STAMPS_DUMP "v_mov_b32 v94, s72\n ds_write_b32 %[lc], v94 offset:1792\n v_mov_b32 v94, s73\n ds_write_b32 %[lc], v94 offset:2048\n" \
-                           "v_mov_b32 v94, s74\n ds_write_b32 %[lc], v94 offset:2304\n v_mov_b32 v94, s75\n ds_write_b32 %[lc], v94 offset:2560\n" \
-                           "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
-#define WA_ASM_STAMPS_CLOBBER "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
-#else
-#define WA_ASM_STAMPS_INIT ""
-#define WA_ASM_STAMPS_DUMP ""
-#define WA_ASM_STAMPS_CLOBBER
-#endif
-// everything behind the loop: the dead-end exit and the pending-event handler (a completed 64-word block and/or the arrival)
-#define WA_ASM_TAIL                                                                                               \
-    "Lwa_dead%=:\n"                                                                                               \
-    "s_mov_b32 %[code], 1\n"                                                                                      \
-    "s_branch Lwa_out%=\n"                                                                                        \
-    "Lwa_event%=:\n"                                                                                              \
-    "s_mov_b32 %[code], 2\n"                                                                                      \
-    "s_and_b32 s46, m0, 63\n"                                                                                     \
-    "s_cbranch_scc1 Lwa_out%=\n"                   /* no complete block: it is the arrival (:182-186) */          \
-    "s_lshl_b32 s46, m0, 2\n"                      /* block [len-64, len) -> path[]: one coalesced 256-byte store */ \
-    "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
-    "v_add_u32 v94, s46, v94\n"                                                                                   \
-    "v_add_u32 v94, 0xffffff00, v94\n"                                                                            \
-    "global_store_dword v94, %[pbuf], %[path]\n"                                                                  \
-    "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
-    "s_cbranch_scc1 Lwa_out%=\n"                   /* ... and arrived with it (code 2) */                         \
-    "s_mov_b32 %[code], 0\n"                                                                                      \
-    "s_add_i32 s46, m0, 64\n"                                                                                     \
-    "s_cmp_gt_i32 s46, %[limit]\n"                                                                                \
-    "s_cbranch_scc1 Lwa_out%=\n"                   /* the next block would pass the table-load / capacity limit: the caller's generic loop goes on */ \
-    "v_add_u32 v94, m0, v64\n"                     /* the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw) */ \
-    "v_add_u32 v94, -1, v94\n"                                                                                    \
-    "s_mov_b32 s46, 0x9e3779b9\n"                                                                                 \
-    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
-    "v_add_u32 v94, %[klo], v94\n"                                                                                \
-    "v_xor_b32 v94, %[khi], v94\n"                                                                                \
-    "v_lshrrev_b32 v95, 16, v94\n"                                                                                \
-    "v_xor_b32 v94, v95, v94\n"                                                                                   \
-    "s_mov_b32 s46, 0x7feb352d\n"                                                                                 \
-    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
-    "v_lshrrev_b32 v95, 15, v94\n"                                                                                \
-    "v_xor_b32 v94, v95, v94\n"                                                                                   \
-    "s_mov_b32 s46, 0x846ca68b\n"                                                                                 \
-    "v_mul_lo_u32 v94, v94, s46\n"                                                                                \
-    "v_lshrrev_b32 v95, 16, v94\n"                                                                                \
-    "v_xor_b32 v94, v95, v94\n"                                                                                   \
-    "v_lshrrev_b32 v94, 1, v94\n"                                                                                 \
-    "v_cvt_f32_u32 v94, v94\n"                                                                                    \
-    "v_mul_f32 %[ub], 0x30000000, v94\n"           /* (float)r / 2^31 (:169) */                                   \
-    "s_lshl_b64 s[54:55], 63, %[g8]\n"             /* the active mask back: evaluate the pending step again */    \
-    "s_cmp_eq_u32 s47, 0\n"                                                                                       \
-    "s_cbranch_scc1 Lwa_redo_a%=\n"                                                                               \
-    "s_cmp_eq_u32 s47, 1\n"                                                                                       \
-    "s_cbranch_scc1 Lwa_redo_b%=\n"                                                                               \
-    "s_cmp_eq_u32 s47, 2\n"                                                                                       \
-    "s_cbranch_scc1 Lwa_redo_c%=\n"                                                                               \
-    "s_branch Lwa_redo_d%=\n"                                                                                     \
-    "Lwa_out%=:\n"                                                                                                \
-    "s_mov_b32 %[len], m0\n"                                                                                      \
-    WA_ASM_STAMPS_DUMP                                                                                            \
-    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-#define WA_ASM_CLOBBERS                                                                                           \
-    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82",  \
-        "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44",     \
-        "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
-        "vcc", "scc", "m0", "memory"
-
-// LAZY: the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the slot's stamp array,
-// clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far
-template <bool LAZY>
-__device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
-                                                 const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
-                                                 int32_t *__restrict__ path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
-                                                 int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
-                                                 int32_t guard_bytes, int32_t stamp_guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
-                                                 int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg)
-{
-    const int lane = threadIdx.x;
-    const int j = lane >> 3, pos = lane & 7;
-    const int k2 = pos < 6 ? 5 - pos : 0;   // edge this lane evaluates; positions 6,7 of a group are padding (never admissible)
-    // lane block b = lane >> 3 fetches the record of neighbour 5 - b: the block that becomes active after a move is
-    // then the POSITION of the picked lane (edge k sits at position 5 - k), one s_lshl away from the pick
-    const int32_t dk = wa_delta(k2, nx, nxy), dj = wa_delta(j < 6 ? 5 - j : 5, nx, nxy);
-    const int32_t limit = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
-    const int32_t table = 1 << hash_log2;
-    // field bases moved back by the guard band: every offset the loop forms is then non-negative
-    const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
-    const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
-    const char *stamp_b = LAZY ? reinterpret_cast<const char *>(stamp) - stamp_guard_bytes : nullptr;
-    {   // lane constants (columns of 64 dwords behind the dummy slots)
-        int32_t *lc = tab + table + 64;
-        lc[0 * 64 + lane] = lane;
-        lc[1 * 64 + lane] = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
-        lc[2 * 64 + lane] = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
-        lc[3 * 64 + lane] = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
-        lc[4 * 64 + lane] = dk;
-        lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
-        lc[6 * 64 + lane] = (table + lane) * 4;                                      // this lane's dummy slot
-        if (LAZY) {
-            lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
-            lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : __float_as_int(R.rho);
-        }
-    }
-    const int32_t lcaddr = (table + 64 + lane) * 4;
-    int32_t cur = st.cur, len = st.len, g8 = 0;
-    int32_t pbuf = st.cur;
-    if (prefix_words) pbuf = lane < (st.len & 63) ? prefix_words[(st.len & ~63) + lane] : 0;
-    float ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
-    float p = -0.f, h = 0.f;
-    if (j == 0 && pos < 6) {
-        const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
-        p = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pher) + boff);
-        h = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(heur) + boff);
-    }
-    uint32_t pd = LAZY ? stamp[cur] : 1u;
-    const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
-    int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on
-    for (;;) {
-        // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
-        if ((len | 63) + 1 > limit) { exit_code = 3; break; }
-        int32_t code;
-        if (!LAZY) {
-            asm volatile(
-                WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT
-                "Lwa_top%=:\n"
-                WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
-                WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
-                WA_ASM_STEP("v71", "v72", "v73", "v74", "c")
-                WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
-                "s_branch Lwa_top%=\n"
-                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-                WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
-                WA_ASM_TAIL
-                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
-                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
-                : WA_ASM_CLOBBERS);
-        } else {
-            asm volatile(
-                WA_ASM_PROLOGUE
-                "ds_read_b32 v99, %[lc] offset:3328\n"        // stamp offset of this lane's neighbour
-                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 0..2: clean value, evap_now + 1, rho
-                "v_mov_b32 v96, %[sio]\n"
-                "s_waitcnt lgkmcnt(0)\n"
-                "v_readlane_b32 s33, v94, 0\n"
-                "v_readlane_b32 s34, v94, 1\n"
-                "v_readlane_b32 s35, v94, 2\n"
-                WA_ASM_STAMPS_INIT
-                "Lwa_top%=:\n"
-                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "a")
-                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "b")
-                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "c")
-                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "d")
-                "s_branch Lwa_top%=\n"
-                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-                WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d")
-                "Lwa_rare_a%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "0")
-                "Lwa_rare_b%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "1")
-                "Lwa_rare_c%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "2")
-                "Lwa_rare_d%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "3")
-                WA_ASM_TAIL
-                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock),
-                  [sio] "+v"(pd)
-                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b)
-                : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", WA_ASM_CLOBBERS);
-        }
-#if defined(WA_ASM_STAMPS)
-        if (dbg && lane == 0) {
-            const int32_t *lcs = tab + table + 64;
-            for (int i = 0; i < 6; i++) atomicAdd(&dbg[i], (unsigned long long)(uint32_t)lcs[(7 + i) * 64]);
-        }
-#endif
-        if (code == 0) continue;   // stopped at a block boundary (the block is stored): the limit test above decides
-        exit_code = code;
-        break;
-    }
-#if defined(WA_ASM_STAMPS)
-    if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
-#endif
-    float L = exit_code == 1 ? INFINITY : ltab[len - 1];   // :78, one add of `precision` per step taken
-    st.done = exit_code != 3;
-    if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
-        if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
-        L = INFINITY;
-        st.done = true;
-    }
-    if (len & 63) {  // partial last block (entries [len & ~63, len))
-        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
-    }
-    st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
-}
+#include "walk_loop_gfx950.hpp"   // wa_walk_fast_asm<LAZY>: the hand-scheduled general step
 
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
 template <int MODE, bool SPARSE>
@@ -1513,7 +1131,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // PUBLISHES what k_rank publishes (global best, perm/depA for the apply pass, trace, the next
 // generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
-template <bool SPARSE>
+template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
                                                         float *dst_base, int32_t E, int32_t gen, int32_t MB)
 {
@@ -1522,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // their latency-bound work hides under the sweep blocks that follow
     if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
         if (!SPARSE) {
-            wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, 6 * D.d.n, R.rho,
+            wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
                           (int32_t)blockIdx.x - MB, E);
         } else {
             // lazy evaporation, background pass: every WA_LAZY_PERIOD-th entry of the dirty list (phase = generation)
@@ -1611,8 +1229,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             for (int32_t i = tid; i < blen; i += blockDim.x) {
                 int32_t w = srcp[i];
                 dstp[i] = w;
-                mark[w & WA_ID_MASK] = ver;
-                pos[w & WA_ID_MASK] = i;
+                mark[w & WaNbT<NB>::IDM] = ver;
+                pos[w & WaNbT<NB>::IDM] = i;
             }
             bestL = iterL;
             changed = true;
@@ -1652,8 +1270,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
     for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += 8 * blockDim.x) {
         int32_t w = path[i];
-        int32_t v = path[i - 1] & WaNbT<6>::IDM;
-        int64_t e = (int64_t)v * 6 + ((uint32_t)w >> WaNbT<6>::SHIFT);
+        int32_t v = path[i - 1] & WaNbT<NB>::IDM;
+        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
         atomicOr(&mask[e], 1ULL << bit);
         if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
             uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
@@ -1907,58 +1525,83 @@ __global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta)
 // Row of best-path node i = 32 floats: thr[26] (admissible ? prob_sum : -inf), total, edge taken to best[i+1],
 // L accumulated on arrival at node i (the in-order sum of the step lengths, which differ per move type here), pad.
 #define WA_ROW26 32
-__global__ __launch_bounds__(64) void k_replay_table26(WaAcsDev D, WaRun R)
+// arrival lengths of the best path: one sequential fp32 chain in walk order (:78).  The step lengths are fetched and
+// classified by the whole block (tiles of 1024 through LDS); thread 0 only adds.
+__device__ __forceinline__ void wa_table26_lengths(const WaAcsDev &D, const WaRun &R, int32_t slot, float *s_d)
 {
-    const int32_t slot = blockIdx.y, lane = threadIdx.x;
+    const WaSlotCtl *ctl = &D.ctl[slot];
+    if (ctl->bestL == INFINITY) return;
+    const int32_t blen = ctl->best_len;
+    const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    float *T = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
+    const float d1 = R.precision, d2 = R.precision * 1.414f, d3 = R.precision * 1.732f;
+    float L = 0.f;
+    if (threadIdx.x == 0) T[28] = L;
+    for (int32_t base = 1; base < blen; base += 1024) {
+        const int32_t cnt = blen - base < 1024 ? blen - base : 1024;
+        for (int32_t q = threadIdx.x; q < cnt; q += blockDim.x) {
+            int px, py, pz;
+            wa_off26((int)((uint32_t)bpath[base + q] >> WaNbT<26>::SHIFT), px, py, pz);
+            const int type = (px != 0) + (py != 0) + (pz != 0);
+            s_d[q] = type == 1 ? d1 : type == 2 ? d2 : d3;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int32_t q = 0; q < cnt; q++) {
+                L += s_d[q];
+                T[(int64_t)(base + q) * WA_ROW26 + 28] = L;
+            }
+        __syncthreads();
+    }
+}
+// One wavefront per best-path node (wave w of n_waves takes nodes w, w + n_waves, ...): the walk's own step evaluation with
+// visited set = best[0..i].  apply_here: the row first applies the pending ranked deposits (mask != 0) of its 26 edges -- same
+// adds, same ascending rank order as wa_apply_body, which skips edges leaving a best-path node when it shares the launch.
+__device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t w, int32_t n_waves, bool apply_here,
+                                                const float *s_dep)
+{
+    const int lane = threadIdx.x & 63;
     const WaSlotCtl *ctl = &D.ctl[slot];
     if (ctl->bestL == INFINITY) return;
     const int32_t blen = ctl->best_len;
     const uint32_t ver = ctl->best_ver;
+    const float lambda = ctl->dep_lambda, Q = ctl->dep_Q, bestL = ctl->dep_bestL;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
     const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
-    const float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    float *pher = D.pher + (int64_t)slot * D.pher_stride;
+    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
     const int k = lane < 26 ? lane : 25;
     int dx, dy, dz;
     wa_off26(k, dx, dy, dz);
     const int32_t dk = dz * D.d.nxy + dy * D.d.nx + dx;
-    if (blockIdx.x == 0) {  // arrival lengths: one sequential fp32 chain in walk order (:78)
-        // the step lengths are fetched and classified by all lanes (tiles of 1024 through LDS); lane 0 only adds
-        __shared__ float s_d[1024];
-        const float d1 = R.precision, d2 = R.precision * 1.414f, d3 = R.precision * 1.732f;
-        float L = 0.f;
-        if (lane == 0) T[28] = L;
-        for (int32_t base = 1; base < blen; base += 1024) {
-            const int32_t cnt = blen - base < 1024 ? blen - base : 1024;
-            for (int32_t q = lane; q < cnt; q += 64) {
-                int px, py, pz;
-                wa_off26((int)((uint32_t)bpath[base + q] >> WaNbT<26>::SHIFT), px, py, pz);
-                const int type = (px != 0) + (py != 0) + (pz != 0);
-                s_d[q] = type == 1 ? d1 : type == 2 ? d2 : d3;
-            }
-            __syncthreads();
-            if (lane == 0)
-                for (int32_t q = 0; q < cnt; q++) {
-                    L += s_d[q];
-                    T[(int64_t)(base + q) * WA_ROW26 + 28] = L;
-                }
-            __syncthreads();
-        }
-        return;
-    }
-    for (int32_t i = blockIdx.x - 1; i < blen - 1; i += gridDim.x - 1) {   // decisions exist at nodes 0 .. blen-2
+    const int32_t last_id = (int32_t)D.d.n - 1;
+    for (int32_t i = w; i < blen - 1; i += n_waves) {   // decisions exist at nodes 0 .. blen-2
         const int32_t v = bpath[i] & WaNbT<26>::IDM;
         float p = -0.f, h = 0.f;
         bool adm = false;
         if (lane < 26) {
-            p = pher[(int64_t)v * 26 + lane];
-            h = heur[(int64_t)v * 26 + lane];
-            if ((__float_as_uint(p) >> 31) == 0) {            // in bounds and free (:148)
-                const int32_t nb = v + dk;
-                adm = !(mark[nb] == ver && pos[nb] <= i);     // not on the prefix best[0..i] (:145-146)
+            const int64_t e = (int64_t)v * 26 + lane;
+            p = pher[e];
+            h = heur[e];
+            int32_t nb = v + dk;
+            nb = nb < 0 ? 0 : nb > last_id ? last_id : nb;    // (an out-of-bounds edge is inadmissible by its sign bit whatever is found here)
+            const uint32_t mk = mark[nb];
+            unsigned long long m = apply_here ? mask[e] : 0ULL;
+            if (m) {  // somebody walked (v, lane): the ranked deposits in ascending rank order (:210-211); v is on the best path (:209)
+                const float bonus = (float)(mk == ver) * lambda * Q / bestL;
+                while (m) {
+                    const int bq = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    p += s_dep[bq] + bonus;
+                }
+                pher[e] = p;
+                mask[e] = 0;
             }
+            if ((__float_as_uint(p) >> 31) == 0)              // in bounds and free (:148)
+                adm = !(mk == ver && pos[nb] <= i);           // not on the prefix best[0..i] (:145-146)
         }
         const float info = wa_powi(fabsf(p), R.alpha) * h;    // :154
         const float a = adm ? info : 0.f;
@@ -1973,6 +1616,33 @@ __global__ __launch_bounds__(64) void k_replay_table26(WaAcsDev D, WaRun R)
         if (lane == 25) row[26] = t;
         if (lane == 0) row[27] = __int_as_float((int32_t)((uint32_t)bpath[i + 1] >> WaNbT<26>::SHIFT));
     }
+}
+__global__ __launch_bounds__(64) void k_replay_table26(WaAcsDev D, WaRun R)
+{
+    __shared__ float s_d[1024];
+    if (blockIdx.x == 0) wa_table26_lengths(D, R, blockIdx.y, s_d);
+    else wa_table26_rows(D, R, blockIdx.y, (int32_t)blockIdx.x - 1, (int32_t)gridDim.x - 1, false, nullptr);
+}
+// Deposit apply + replay table of the 26-neighbour search in ONE launch, like k_apply_table: block 0 = arrival lengths,
+// blocks [1, 1 + WA_TABLE26_BLOCKS) = table rows (four wavefronts each) that also apply the deposits on edges leaving a
+// best-path node, the rest = the ordinary apply pass, which skips exactly those edges.
+#define WA_TABLE26_BLOCKS 64
+__global__ __launch_bounds__(256) void k_apply_table26(WaAcsDev D, WaRun R)
+{
+    __shared__ float s_d[1024];
+    __shared__ float s_dep[64];
+    const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    if (blockIdx.x == 0) { wa_table26_lengths(D, R, slot, s_d); return; }
+    if ((int32_t)blockIdx.x <= WA_TABLE26_BLOCKS) {
+        const float dep_mine = (tid < 64 && tid < D.max_colony) ? D.depA[(int64_t)slot * D.max_colony + tid] : 0.f;
+        const int32_t n_dep = D.ctl[slot].n_dep;
+        if (tid < 64) s_dep[tid] = tid < n_dep ? dep_mine : 0.f;
+        __syncthreads();
+        wa_table26_rows(D, R, slot, ((int32_t)blockIdx.x - 1) * 4 + (tid >> 6), WA_TABLE26_BLOCKS * 4, true, s_dep);
+        return;
+    }
+    const int32_t ab = (int32_t)blockIdx.x - 1 - WA_TABLE26_BLOCKS;  // (bx = ab & 7, rank bit = ab >> 3)
+    wa_apply_body<26>(D, slot, 0, ab >> 3, ab & 7, 8, true, s_dep);
 }
 
 // one lane per node, 64 nodes per ballot.  Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).

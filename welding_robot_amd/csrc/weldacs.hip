@@ -59,6 +59,7 @@ struct wa_acs {
     int cur_buf;
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
+    bool lds_attr_set;
     WaRun R;
     bool begun;
     bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
