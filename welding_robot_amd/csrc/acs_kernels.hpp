@@ -610,7 +610,21 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         }
 #endif
         st.len = node + 1;
-        for (int32_t q = lane; q < st.len; q += 64) path[q] = bpath[q];  // the walked prefix IS the best path's
+        // the walked prefix IS the best path's.  512 words per round: eight independent loads per lane, then eight stores
+        // (a load-store pair per round would put one memory round trip per 64 words on every converged walk)
+        for (int32_t q0 = 0; q0 < st.len; q0 += 512) {
+            int32_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t q = q0 + u * 64 + lane;
+                w[u] = q < st.len ? bpath[q] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t q = q0 + u * 64 + lane;
+                if (q < st.len) path[q] = w[u];
+            }
+        }
         if (what != 3) {  // finished on the replay track
             // arriving over the whole best path accumulates exactly the steps that produced best.L
             const float L = what == 2 ? bestL : INFINITY;

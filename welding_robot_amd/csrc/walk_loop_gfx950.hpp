@@ -41,7 +41,9 @@
 #else
 #define WA_ASM_STAMP(i) ""
 #endif
-// One step.  CP/CH = records of `cur` (arrived or arriving), NP/NH = where the neighbours' records go, X = label suffix.
+// One step.  CP/CH = records of `cur` (requested by the step before the previous one's tail, arrived or arriving); the
+// records of the NEXT voxel's neighbours are requested into the same registers as soon as that voxel is known (the
+// step in between runs on the other register set NP/NH).  X = label suffix.
 // Schedule rules (measured with tools/ubench/issue_rates.hip, one wave alone on its SIMD): every instruction costs
 // ~4.3 cycles; an SALU instruction reading an SGPR/VCC that a VALU instruction wrote stalls ~16 cycles unless four
 // other instructions sit between them; a conditional branch costs ~13 cycles not taken, ~23 taken.  Hence: compares
@@ -81,12 +83,7 @@
 #define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT)
 #define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n")
 #define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT)                                       \
-    "s_mul_i32 s40, %[cur], 24\n"                                                                                 \
-    "v_add_u32 v82, s40, v65\n"                                                                                   \
-    "global_load_dword " NP ", v82, %[pher]\n"                    /* records of the six neighbours: needed next step */ \
-    "global_load_dword " NH ", v82, %[heur]\n"                                                                    \
-    HEAD(NS)                                                                                                      \
-    WA_ASM_WARM_ADDR                                                                                              \
+    WA_ASM_WARM_ADDR                                              /* (s40 = cur * 24 since the previous step's tail) */ \
     "Lwa_redo_" X "%=:\n"                                                                                         \
     WA_ASM_STAMP(72)                                                                                              \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
@@ -138,6 +135,11 @@
     "s_lshl_b32 %[g8], s45, 3\n"                                  /* next active block = position of the pick (low 6 bits count) */ \
     "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
+    "s_mul_i32 s40, %[cur], 24\n"                                 /* records of the new voxel's six neighbours: needed by the step after */ \
+    "v_add_u32 v82, s40, v65\n"                                   /* the next one; they go where this step's records were */ \
+    "global_load_dword " CP ", v82, %[pher]\n"                                                                    \
+    "global_load_dword " CH ", v82, %[heur]\n"                                                                    \
+    HEAD(CS)                                                                                                      \
     "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
     "v_add_u32 v77, s41, v67\n"                                                                                   \
     "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
@@ -191,7 +193,11 @@
     "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
     "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
     "ds_read_b32 v75, v77\n"                                                                                      \
-    "v_add_u32 v76, %[cur], v68\n"
+    "v_add_u32 v76, %[cur], v68\n"                                                                                \
+    "s_mul_i32 s40, %[cur], 24\n"                /* records of cur's six neighbours: what the first step's tail would have requested */ \
+    "v_add_u32 v82, s40, v65\n"                                                                                   \
+    "global_load_dword v73, v82, %[pher]\n"                                                                       \
+    "global_load_dword v74, v82, %[heur]\n"
 #if defined(WA_ASM_STAMPS)
 #define WA_ASM_STAMPS_INIT "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n" \
                            "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
@@ -341,6 +347,9 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                 "v_readlane_b32 s33, v94, 0\n"
                 "v_readlane_b32 s34, v94, 1\n"
                 "v_readlane_b32 s35, v94, 2\n"
+                "s_lshl_b32 s46, %[cur], 2\n"
+                "v_add_u32 v98, s46, v99\n"
+                "global_load_dword v97, v98, %[stamp]\n"
                 WA_ASM_STAMPS_INIT
                 "Lwa_top%=:\n"
                 WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "a")
