@@ -171,6 +171,9 @@ int wa_acs_read_pheromone(wa_acs *s, int32_t slot, float *out /* nvox*6 */);
 /* the agents[] of the generation walked last (ACSRank_3D.hpp:251-261): per ant L (+inf = dead end, :88-91) and node
  * count (Agent::getPath()->size()); *colony = ants of that generation, of which min(colony, cap) are written. */
 int wa_acs_read_ants(wa_acs *s, int32_t slot, int32_t *colony, float *L, int32_t *len, int32_t cap);
+/* the node ids one ant of that generation visited, start first (Agent::getPath(), ACSRank_3D.hpp:34,75-77): *len = node
+ * count, of which min(*len, cap) ids are written. */
+int wa_acs_read_ant_path(wa_acs *s, int32_t slot, int32_t ant, int32_t *ids, int32_t cap, int32_t *len);
 int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, float *Q);
 
 /* kernel timing with HIP events on the context stream.  Enable before wa_acs_run; afterwards

@@ -90,6 +90,8 @@ def lib():
         L.wo_acs_pheromone.restype = C.POINTER(C.c_float)
         L.wo_acs_pheromone.argtypes = [C.c_void_p]
         L.wo_acs_last_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wo_acs_last_paths.restype = None
+        L.wo_acs_last_paths.argtypes = [C.c_void_p, C.c_void_p]
         L.wo_acs_last_ants.restype = C.c_int32
         L.wo_acs_last_ants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.wo_acs_heuristic.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
@@ -295,6 +297,13 @@ class Acs:
         lens, L = np.empty(n, np.int32), np.empty(n, np.float32)
         lib().wo_acs_last_ants(self.h, lens.ctypes.data, L.ctypes.data)
         return lens, L
+
+    def last_paths(self):
+        """node ids of every ant of the last generation, one array per ant"""
+        lens, _ = self.last_ants()
+        ids = np.empty(int(lens.sum()), np.int32)
+        lib().wo_acs_last_paths(self.h, ids.ctypes.data)
+        return np.split(ids, np.cumsum(lens)[:-1])
 
     def heuristic(self, end_id, beta=0.6):
         out = np.empty(self.grid.n * self.nb, np.float32)

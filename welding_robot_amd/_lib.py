@@ -67,6 +67,7 @@ SYMBOLS = {
     "wa_acs_export_trace": (C.c_int, [_V, _V, _I, _I]),
     "wa_acs_read_pheromone": (C.c_int, [_V, _I, _P]),
     "wa_acs_read_ants": (C.c_int, [_V, _I, _P, _P, _P, _I]),
+    "wa_acs_read_ant_path": (C.c_int, [_V, _I, _I, _P, _I, _P]),
     "wa_acs_last_params": (C.c_int, [_V, _I, _P, _P, _P]),
     "wa_acs_profile": (C.c_int, [_V, _I, _I]),
     "wa_acs_profile_read": (C.c_int, [_V, _P, _P]),

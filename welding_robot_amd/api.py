@@ -248,6 +248,14 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_read_ants(self.h, slot, C.byref(c), _ptr(Ls), _ptr(lens), c.value))
         return Ls, lens
 
+    def ant_path(self, ant, slot=0):
+        """node ids visited by one ant of the generation walked last (Agent::getPath())"""
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.wa_acs_read_ant_path(self.h, slot, ant, None, 0, C.byref(n)))
+        ids = np.empty(n.value, np.int32)
+        self.ctx.check(self.ctx.lib.wa_acs_read_ant_path(self.h, slot, ant, _ptr(ids), n.value, C.byref(n)))
+        return ids
+
     def last_params(self, slot=0):
         c, l, q = C.c_int32(), C.c_float(), C.c_float()
         self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))

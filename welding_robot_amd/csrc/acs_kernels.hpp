@@ -258,6 +258,9 @@ struct WaWalkState {
     uint32_t step;
     float L;
     bool done;
+    int reason;   // why an unfinished walk came back from the fast loop: 0 = its limits (table load, capacity), 4 = rejoin watch
+    int32_t pbuf; // ... and the words of its incomplete 64-word block (lane i = word i of the block), for the re-entry
+    bool pbuf_valid;
 };
 
 // fast path: hash tabu only.  Returns with st.done set, or with st.done clear when the table
@@ -583,11 +586,66 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32
     }
 }
 
+// ------------------------------------------------------------------ back onto the replay track after a detour
+// An ant that left the best path and came back to it stands on best[q] with its own visited set V (its tabu hash).  Row j
+// of the replay table was built for the visited set best[0..j]; it says what THIS ant would do at best[j] iff the two sets
+// agree on the six neighbours of best[j]:  a neighbour the row treats as admissible must not be in V (a detour node next
+// to the path), and a neighbour the row treats as visited-because-on-the-prefix must be in V or be one of best[q..j-1],
+// which the ant visits on the way (a path node the detour skipped is not).  64 rows are checked at once, one lane per
+// row: six LDS probes of V, the position of a skipped-looking neighbour from bestpos[], then the usual draw-against-
+// thresholds test.  Returns 1 dead end at best[stop], 2 arrived (stop = last node), 3 the ant has to take a general step
+// at best[stop] (its draw leaves the path there, or the row does not apply to it); rows q .. stop-1 were followed.
+__device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const int32_t *__restrict__ bpath, const uint8_t *__restrict__ btabu,
+                                              const int32_t *__restrict__ pos, int32_t blen, int32_t q, uint32_t step_q, uint64_t antkey,
+                                              const WaTabu &V, int32_t nx, int32_t nxy, int32_t max_rows, int32_t &stop)
+{
+    const int lane = threadIdx.x;
+    const float4 *__restrict__ T4 = reinterpret_cast<const float4 *>(T);
+    const int32_t last = blen - 1;                      // decisions exist at nodes 0 .. last-1
+    const int32_t lim = q + max_rows < last ? q + max_rows : last;
+    for (int32_t j0 = q;; j0 += 64) {
+        const int32_t j = j0 + lane;
+        const bool live = j < lim;
+        const int32_t jj = live ? j : (q < last ? q : last - 1);
+        const float4 a = T4[2 * jj], b = T4[2 * jj + 1];
+        const int32_t v = bpath[jj] & (int32_t)WA_ID_MASK;
+        const uint32_t bt = btabu[jj];
+        const float thr[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+        bool applies = true;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const bool adm = thr[k] != -INFINITY;       // (a NaN threshold -- seam, Q3 -- is an admissible edge)
+            const bool pre = (bt >> k) & 1u;
+            if (live && (adm || pre)) {                 // either way the neighbour is in bounds
+                const int32_t nb = v + wa_delta(k, nx, nxy);
+                const bool inV = tabu_has(V, nb);
+                if (adm) applies = applies && !inV;
+                else if (!inV) { const int32_t ps = pos[nb]; applies = applies && ps >= q && ps <= j; }
+            }
+        }
+        float rnd = (float)wa_ctr_draw(antkey, step_q + (uint32_t)(j - q)) / 2147483648.0f;   // (float)rand()/(float)RAND_MAX (:169)
+        rnd *= b.z;                                                                             // :170, total
+        const int nk = __float_as_int(b.w);
+        const uint32_t h = (a.x >= rnd ? 1u : 0u) | (a.y >= rnd ? 2u : 0u) | (a.z >= rnd ? 4u : 0u) | (a.w >= rnd ? 8u : 0u) |
+                           (b.x >= rnd ? 16u : 0u) | (b.y >= rnd ? 32u : 0u);
+        const int pick = h ? 31 - __clz((int)h) : -1;
+        const unsigned long long fm = __ballot(live && (!applies || pick != nk));
+        if (fm != 0) {
+            const int g = __ffsll((long long)fm) - 1;
+            stop = j0 + g;
+            const bool ok_row = (__ballot(applies) >> g) & 1ULL;
+            return (ok_row && __builtin_amdgcn_readlane((int)h, g) == 0) ? 1 : 3;
+        }
+        if (j0 + 64 >= lim) { stop = lim; return lim == last ? 2 : 3; }
+    }
+}
+
 template <int MODE, bool ALPHA1, bool SPARSE>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
-                                            int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags)
+                                            int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags,
+                                            uint32_t best_ver = 0)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
@@ -597,7 +655,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     WaWalkState st;
-    st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false;
+    st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false; st.pbuf = 0; st.pbuf_valid = false;
     const int32_t *prefix_words = nullptr;
     if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
@@ -667,8 +725,53 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #ifndef WA_STAMPS
     use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
 #endif
-    if (st.len < fast_limit && use_asm)
-        wa_walk_fast_asm<SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+    if (st.len < fast_limit && use_asm && !SPARSE && prefix_words && (walk_flags & 2)) {
+        // The ant replayed a prefix of the best path and left it.  Measured: such an ant is back on the path after a
+        // median of 3-4 steps and 82-92 % of its remaining nodes lie on it, so the general loop runs with a rejoin watch and every
+        // time the ant is found on the path again it goes back onto the replay track for as long as the table applies to it.
+        const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+        const int32_t *bpos = D.bestpos + (int64_t)slot * D.d.n;
+        const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
+        const float *RT = D.rtab + (int64_t)slot * D.path_cap * 8;
+        int32_t hold = ((walk_flags >> 8) & 0xffff) ? ((walk_flags >> 8) & 0xffff) : 1, backoff = 1;
+        for (;;) {
+            wa_walk_fast_asm<2>(R, pher, heur, nullptr, 0.f, 0u, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at, D.guard_bytes, 0,
+                                D.ltab, st, flags_out, prefix_words, nullptr, mark, (walk_flags & 8) ? 0u : best_ver, hold);
+            prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
+            if (st.done || st.reason != 4) break;
+            int32_t gained = 0;
+            const int32_t q = mark[st.cur] == best_ver ? bpos[st.cur] : -1;
+            if (q >= 0 && q < rlen - 1 && !(walk_flags & 4)) {
+                int32_t room = spill_at - st.len;                 // nodes the tabu hash / the path may still take
+                if ((int32_t)D.path_cap - st.len < room) room = (int32_t)D.path_cap - st.len;
+                int32_t stop = q;
+                const int kind = room > 0 ? wa_replay_from(RT, bpath, btabu, bpos, rlen, q, (uint32_t)(st.len - 1), antkey, T, D.d.nx, D.d.nxy, room, stop) : 3;
+                gained = stop - q;
+                for (int32_t t = lane; t < gained; t += 64) {     // the ant walked best[q+1 .. stop]: path words (:76-77) and tabu set (:75)
+                    const int32_t w = bpath[q + 1 + t];
+                    path[st.len + t] = w;
+                    const int32_t key = w & (int32_t)WA_ID_MASK;
+                    uint32_t hh = ((uint32_t)key * 2654435761u) >> T.shift;
+                    while (atomicCAS(&tab[hh], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) hh = (hh + 1) & T.mask;
+                }
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+                st.len += gained;
+                if (gained > 0) st.pbuf_valid = false;
+                st.step = (uint32_t)(st.len - 1);
+                st.cur = bpath[stop] & (int32_t)WA_ID_MASK;
+                st.L = D.ltab[st.len - 1];
+                if (kind == 2) { st.done = true; break; }                       // arrived over the rest of the best path
+                if (kind == 1) { st.L = INFINITY; st.done = true; break; }      // no candidate at best[stop] (:162-166, :191-192)
+            }
+            if (gained > 0) { backoff = 1; hold = 1; }
+            else { hold = backoff; backoff = backoff < 32 ? backoff * 2 : 32; }   // the table does not apply here: walk on before asking again
+            if (st.len >= fast_limit) break;
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else if (st.len < fast_limit && use_asm)
+        wa_walk_fast_asm<SPARSE ? 1 : 0>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
@@ -748,7 +851,8 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
         const uint32_t mk = (apply_here || rebuild) ? mark[nbid] : 0u;
         uint32_t bt;
         if (rebuild) {   // neighbour k2 is tabu for an ant standing on best[i] that came along the path iff it lies on best[0..i]
-            const bool on = k2 < 6 && mk == ver && pos[nbid] <= i;
+            // (only for a neighbour id inside the field: wa_replay_from looks such a neighbour up by its id)
+            const bool on = k2 < 6 && nbid == v + dk && mk == ver && pos[nbid] <= i;
             bt = (uint32_t)(__ballot(on) >> (threadIdx.x & 48)) & 0x3fu;   // the six lanes of this 16-lane row
             if (k2 == 0) btabu[i] = (uint8_t)bt;
         } else {
@@ -830,8 +934,11 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     int32_t f = 0, b = 0;
     const float bestL = c->bestL;
     const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
+    // the rejoin watch pays once the colony has settled on the best path (it costs a failed attempt every few steps while the
+    // ants still explore): it is switched on when that path has not changed for a number of generations
+    if (gen - c->tabu_gen < ((walk_flags >> 24) & 127)) walk_flags &= ~2;
     wa_walk_one<1, ALPHA1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
-                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags);
+                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw

@@ -80,14 +80,34 @@
     "Lwa_dirty2_" X "%=:\n"                                                                                       \
     "v_mul_f32 v78, v78, " CH "\n"                                                                                \
     "s_branch Lwa_info_" X "%=\n"
-#define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT)
-#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n")
-#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT)                                       \
+// rejoin watch (ants that left the best path after replaying a prefix of it, wa_walk_one): the membership stamp of the voxel
+// the ant stands on is fetched with a scalar load and looked at one step later -- when it says "on the best path" (and the
+// hold-off counter has run out) the loop hands back to the caller, who tries to put the ant back on the replay track
+#define WA_ASM_REJ_NONE(X) ""
+#define WA_ASM_REJ_WATCH(X)                                                                                       \
+    "s_sub_u32 s81, s81, 1\n"                                     /* steps left before a rejoin may be reported */ \
+    "s_cmp_eq_u32 s78, s80\n"                                     /* the voxel we stood on one step ago: on the best path? */ \
+    "s_cselect_b32 s82, s81, 1\n"                                                                                 \
+    "s_cmp_le_i32 s82, 0\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_rej_" X "%=\n"                                                                            \
+    "s_lshl_b32 s83, %[cur], 2\n"                                                                                 \
+    "s_load_dword s78, %[markb], s83\n"
+#define WA_ASM_REJ_EXIT(CP, CH, X)                                                                                \
+    "Lwa_rej_" X "%=:\n"                                                                                          \
+    "v_mov_b32 %[pio], " CP "\n"                                                                                  \
+    "v_mov_b32 %[hio], " CH "\n"                                                                                  \
+    "s_mov_b32 %[code], 4\n"                                                                                      \
+    "s_branch Lwa_out%=\n"
+#define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_NONE)
+#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_WATCH)
+#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_NONE)
+#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ)                                  \
     WA_ASM_WARM_ADDR                                              /* (s40 = cur * 24 since the previous step's tail) */ \
     "Lwa_redo_" X "%=:\n"                                                                                         \
     WA_ASM_STAMP(72)                                                                                              \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
     WA_ASM_STAMP(73)                                                                                              \
+    REJ(X)                                                                                                        \
     "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
     "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
     VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
@@ -267,16 +287,20 @@
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
 
-// LAZY: the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the slot's stamp array,
-// clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far
-template <bool LAZY>
+// VARIANT 0: dense field.  1 (LAZY): the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the
+// slot's stamp array, clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far.
+// 2: dense field + rejoin watch: `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
+// st.reason = 4 when the loop handed back because the ant stood on the best path one step ago.
+template <int VARIANT>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
-                                                 int32_t *__restrict__ path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
+                                                 int32_t *path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
                                                  int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
                                                  int32_t guard_bytes, int32_t stamp_guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
-                                                 int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg)
+                                                 int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg,
+                                                 const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0)
 {
+    constexpr bool LAZY = VARIANT == 1, REJOIN = VARIANT == 2;
     const int lane = threadIdx.x;
     const int j = lane >> 3, pos = lane & 7;
     const int k2 = pos < 6 ? 5 - pos : 0;   // edge this lane evaluates; positions 6,7 of a group are padding (never admissible)
@@ -302,11 +326,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
             lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : __float_as_int(R.rho);
         }
+        if (REJOIN) lc[14 * 64 + lane] = lane == 0 ? (int32_t)ver : hold_off;
     }
     const int32_t lcaddr = (table + 64 + lane) * 4;
     int32_t cur = st.cur, len = st.len, g8 = 0;
     int32_t pbuf = st.cur;
-    if (prefix_words) pbuf = lane < (st.len & 63) ? prefix_words[(st.len & ~63) + lane] : 0;
+    if (REJOIN && st.pbuf_valid) pbuf = st.pbuf;
+    else if (prefix_words)   // (through L2: the words may have been stored by this very wavefront a moment ago)
+        pbuf = lane < (st.len & 63) ? __hip_atomic_load(&prefix_words[(st.len & ~63) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     float ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
     float p = -0.f, h = 0.f;
     if (j == 0 && pos < 6) {
@@ -321,7 +348,29 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
         int32_t code;
-        if (!LAZY) {
+        if (REJOIN) {
+            asm volatile(
+                WA_ASM_PROLOGUE
+                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 0, 1: best-path version, hold-off
+                "s_mov_b32 s78, -1\n"                         // (no voxel looked up yet: a version number never gets that far)
+                "s_waitcnt lgkmcnt(0)\n"
+                "v_readlane_b32 s80, v94, 0\n"
+                "v_readlane_b32 s81, v94, 1\n"
+                "Lwa_top%=:\n"
+                WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a")
+                WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b")
+                WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "c")
+                WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "d")
+                "s_branch Lwa_top%=\n"
+                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
+                WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
+                WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
+                WA_ASM_TAIL
+                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
+                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
+                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark)
+                : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
+        } else if (!LAZY) {
             asm volatile(
                 WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT
                 "Lwa_top%=:\n"
@@ -380,11 +429,21 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         exit_code = code;
         break;
     }
+    st.reason = 0;
+    if (exit_code == 4) {   // handed back by the rejoin watch, at the head of a step
+        // a block completed by the last step is still in pbuf (its store belongs to the step that was not run); storing it
+        // again after a boundary that was already handled is harmless.  No step at all (the watch fired on the second look at
+        // the first step, after a probe collision): whoever brought the walk here stored the block, pbuf is empty.
+        if ((len & 63) == 0 && len != st.len) path[(len - 64) + lane] = pbuf;
+        if (cur == end) exit_code = 2;                       // ... which had arrived (:182-186)
+        else if (len >= limit) exit_code = 3;
+        else st.reason = 4;
+    }
 #if defined(WA_ASM_STAMPS)
     if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
 #endif
     float L = exit_code == 1 ? INFINITY : ltab[len - 1];   // :78, one add of `precision` per step taken
-    st.done = exit_code != 3;
+    st.done = exit_code != 3 && exit_code != 4;
     if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
         L = INFINITY;
@@ -394,5 +453,6 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
     }
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
+    st.pbuf = (len & 63) ? pbuf : 0; st.pbuf_valid = true;
 }
 
