@@ -1,7 +1,7 @@
 """Debug aid: first generation / ant / node where the device walk differs from the oracle on the C3 workload (DEV mode)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from welding_robot_amd import api
 import oracle_lib as O
 
