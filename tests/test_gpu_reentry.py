@@ -31,18 +31,23 @@ KNOBS = {
     "hand back only, anywhere, every 2+ steps": dict(WA_REENTRY_STABLE="0", WA_REENTRY="2", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="2"),
     "hand back anywhere, re-enter when on the path": dict(WA_REENTRY_STABLE="0", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="3"),
     "first hand back after 61 steps": dict(WA_REENTRY_STABLE="0", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="61"),
+    # tiny tabu hash (spills to the bitmap after 96 nodes): probe chains longer than the longest hold-off (32) -- the watch
+    # must count steps, not evaluation passes, or an ant on the best path never gets its step done
+    "tiny hash, long probe chains": dict(WA_REENTRY_STABLE="0", WA_HASH_LOG2="7"),
+    "tiny hash, hand back anywhere": dict(WA_REENTRY_STABLE="0", WA_HASH_LOG2="7", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="2"),
     "product default": dict(),
     "off": dict(WA_REENTRY="0"),
 }
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("knobs", list(KNOBS), ids=list(KNOBS))
 @pytest.mark.parametrize("n,occ,ants,gens", [(40, 0.12, 48, (3, 14, 45)), (64, 0.0, 64, (30,))])
 def test_every_ant_every_path_word_equals_the_oracle(ctx, knobs, n, occ, ants, gens):
     og = O.synth_grid(n, seed=77, occ_prob=occ)
     free = np.nonzero(og.free)[0]
     sid, eid = int(free[0]), int(free[-1])
-    old = {k: os.environ.get(k) for k in ("WA_REENTRY", "WA_REENTRY_STABLE", "WA_REENTRY_ANYWHERE", "WA_REENTRY_HOLD")}
+    old = {k: os.environ.get(k) for k in ("WA_REENTRY", "WA_REENTRY_STABLE", "WA_REENTRY_ANYWHERE", "WA_REENTRY_HOLD", "WA_HASH_LOG2")}
     os.environ.update(KNOBS[knobs])
     try:
         dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)

@@ -103,11 +103,11 @@
 #define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_NONE)
 #define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ)                                  \
     WA_ASM_WARM_ADDR                                              /* (s40 = cur * 24 since the previous step's tail) */ \
-    "Lwa_redo_" X "%=:\n"                                                                                         \
     WA_ASM_STAMP(72)                                                                                              \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
     WA_ASM_STAMP(73)                                                                                              \
-    REJ(X)                                                                                                        \
+    REJ(X)                                                        /* once per step: a re-evaluation (collision, block boundary) enters below */ \
+    "Lwa_redo_" X "%=:\n"                                                                                         \
     "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
     "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
     VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
@@ -182,6 +182,7 @@
     "v_and_b32 v77, %[hm4], v77\n"                                                                                \
     "ds_read_b32 v75, v77\n"                                                                                      \
     "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
     "s_branch Lwa_redo_" X "%=\n"
 // no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
 // CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
@@ -432,8 +433,9 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     st.reason = 0;
     if (exit_code == 4) {   // handed back by the rejoin watch, at the head of a step
         // a block completed by the last step is still in pbuf (its store belongs to the step that was not run); storing it
-        // again after a boundary that was already handled is harmless.  No step at all (the watch fired on the second look at
-        // the first step, after a probe collision): whoever brought the walk here stored the block, pbuf is empty.
+        // again after a boundary that was already handled is harmless.  (The watch looks once per step and never before the
+        // first one -- s78 starts at -1 -- so at least one step was taken; the test on len keeps an empty pbuf from ever being
+        // stored over a block that whoever brought the walk here had already written.)
         if ((len & 63) == 0 && len != st.len) path[(len - 64) + lane] = pbuf;
         if (cur == end) exit_code = 2;                       // ... which had arrived (:182-186)
         else if (len >= limit) exit_code = 3;
