@@ -31,6 +31,9 @@ def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=
     P = len(point_ids)
     pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
     mine = wd.shard_problems(len(pairs), rank, world)
+    # searches with the same end point share one heuristic field inside a batch (wa_acs_begin): run them side by side.
+    # (Results do not depend on the order: every search draws from the stream of its global pair index.)
+    mine = sorted(mine, key=lambda k: (pairs[k][1], pairs[k][0]))
     colony = fixed_colony or max(1, int(0.35 * predict / float(grid.precision)))
     t_create = time.perf_counter()
     solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony, lazy=lazy)

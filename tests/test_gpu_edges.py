@@ -200,3 +200,31 @@ def test_hand_scheduled_walk_loop_equals_the_compiler_scheduled_one(ctx):
     (x, px, tx), (y, py, ty) = res
     assert np.array_equal(x[1], y[1]) and np.array_equal(bits(x[0]), bits(y[0])) and np.array_equal(bits(px), bits(py))
     assert np.array_equal(tx["steps"], ty["steps"])
+
+
+def test_searches_with_the_same_end_point_share_one_heuristic_field(ctx):
+    """wa_acs_begin computes one (1 + beta*cos) field (ACSRank_3D.hpp:151-154) per distinct END point of a batch and keeps a
+    slot's field across batches while end point and beta stay the same.  Every search must still equal its own oracle run:
+    duplicates inside a batch, a second batch that reuses and re-assigns fields, a changed beta, a changed end point."""
+    og = box_grid(14, 12, 11, occ_prob=0.1, seed=9)
+    og.free[0] = og.free[-1] = og.free[5] = og.free[100] = 1
+    n = 14 * 12 * 11
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, n_slots=4, max_colony=10)
+    batches = [
+        (0.6, [0, 5, 100, 5], [n - 1, n - 1, 0, 0]),        # slots 0,1 share; 2,3 share
+        (0.6, [100, 0, 5, 0], [n - 1, 0 + 5, 0, n - 1]),    # slot 0 keeps its field, 1 needs a new one, 2 keeps, 3 reads slot 0's
+        (0.9, [0, 5], [n - 1, n - 1]),                      # another beta: nothing may be kept
+        (0.9, [5, 0], [0, n - 1]),                          # slot 0's end point changes, slot 1 keeps
+    ]
+    for b, (beta, starts, ends) in enumerate(batches):
+        p = api.default_params(max_iteration=9, predict=30.0, fixed_colony=10, rng_mode=api.RNG_DEV, seed=40 + b, beta=beta)
+        s.init_pheromone(1.0)
+        s.solve(p, starts, ends, streams=list(range(10 * b, 10 * b + len(starts))))
+        for q, (sid, eid) in enumerate(zip(starts, ends)):
+            a = O.Acs(og)
+            tr = a.solve(sid, eid, 9, 30.0, fixed_colony=10, mode=O.DEV, seed=40 + b, stream=10 * b + q, beta=beta)
+            t = s.trace(q)
+            assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), (b, q)
+            assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), (b, q)
+    s.close()

@@ -42,8 +42,9 @@ KNOBS = {
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("knobs", list(KNOBS), ids=list(KNOBS))
+@pytest.mark.parametrize("lazy", [False, True], ids=["dense sweep", "lazy evaporation"])
 @pytest.mark.parametrize("n,occ,ants,gens", [(40, 0.12, 48, (3, 14, 45)), (64, 0.0, 64, (30,))])
-def test_every_ant_every_path_word_equals_the_oracle(ctx, knobs, n, occ, ants, gens):
+def test_every_ant_every_path_word_equals_the_oracle(ctx, knobs, n, occ, ants, gens, lazy):
     og = O.synth_grid(n, seed=77, occ_prob=occ)
     free = np.nonzero(og.free)[0]
     sid, eid = int(free[0]), int(free[-1])
@@ -52,7 +53,7 @@ def test_every_ant_every_path_word_equals_the_oracle(ctx, knobs, n, occ, ants, g
     try:
         dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
         for g in gens:
-            s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=ants)       # (the knobs are read when the solver is created)
+            s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=ants, lazy=lazy)   # (the knobs are read when the solver is created)
             p = api.default_params(max_iteration=g, predict=float(3 * n), fixed_colony=ants, rng_mode=api.RNG_DEV, seed=5)
             s.init_pheromone(1.0)
             s.solve(p, sid, eid, streams=[3])

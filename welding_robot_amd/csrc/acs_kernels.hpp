@@ -92,11 +92,13 @@ __global__ __launch_bounds__(256) void k_init_pheromone(WaAcsDev D, int32_t slot
 }
 
 // ------------------------------------------------------------------ heuristic field
-__global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta)
+// (1 + beta*cos) of :151-154 is a function of the voxel, the edge and the END point only: wa_acs_begin computes one field per
+// distinct end point of its batch (`slots` = the slots that own one) and every search reads the field ctl.heur_slot names
+__global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta, const int32_t *slots)
 {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= D.d.n) return;
-    int32_t slot = blockIdx.y;
+    int32_t slot = slots[blockIdx.y];
     int32_t end = D.ctl[slot].end;
     int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
     int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
@@ -131,7 +133,7 @@ __device__ __forceinline__ void wa_next_params(WaSlotCtl &c, const WaRun &R, int
 }
 
 __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long *starts,
-                        const long long *ends, const uint32_t *streams)
+                        const long long *ends, const uint32_t *streams, const int32_t *heur_slots)
 {
     int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_problems) return;
@@ -139,6 +141,7 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.start = (int32_t)starts[slot];
     c.end = (int32_t)ends[slot];
     c.stream = streams ? streams[slot] : (uint32_t)slot;
+    c.heur_slot = heur_slots[slot];
     c.clean[0] = c.clean[c.gen & 1];   // lazy evaporation: the field's clean value carries over; generation parity restarts
     c.evap_base += (uint32_t)c.gen;    // ... and so does the count of evaporations applied so far
     c.gen = 0;
@@ -649,7 +652,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
     const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
@@ -725,7 +728,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #ifndef WA_STAMPS
     use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
 #endif
-    if (st.len < fast_limit && use_asm && !SPARSE && prefix_words && (walk_flags & 2)) {
+    if (st.len < fast_limit && use_asm && prefix_words && (walk_flags & 2)) {
         // The ant replayed a prefix of the best path and left it.  Measured: such an ant is back on the path after a
         // median of 3-4 steps and 82-92 % of its remaining nodes lie on it, so the general loop runs with a rejoin watch and every
         // time the ant is found on the path again it goes back onto the replay track for as long as the table applies to it.
@@ -735,8 +738,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         const float *RT = D.rtab + (int64_t)slot * D.path_cap * 8;
         int32_t hold = ((walk_flags >> 8) & 0xffff) ? ((walk_flags >> 8) & 0xffff) : 1, backoff = 1;
         for (;;) {
-            wa_walk_fast_asm<2>(R, pher, heur, nullptr, 0.f, 0u, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at, D.guard_bytes, 0,
-                                D.ltab, st, flags_out, prefix_words, nullptr, mark, (walk_flags & 8) ? 0u : best_ver, hold);
+            wa_walk_fast_asm<SPARSE ? 3 : 2>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+                                             D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, (walk_flags & 8) ? 0u : best_ver, hold);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
             if (st.done || st.reason != 4) break;
             int32_t gained = 0;
@@ -823,7 +826,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     const bool rebuild = ctl->tabu_gen + 1 == ctl->gen;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
-    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
     const int32_t dk = wa_delta(kk, D.d.nx, D.d.nxy);
     const int32_t last_id = (int32_t)D.d.n - 1;
@@ -1617,11 +1620,11 @@ __global__ __launch_bounds__(256) void k_init_pheromone26(WaAcsDev D, int32_t sl
     D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
 }
 
-__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta)
+__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta, const int32_t *slots)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= D.d.n * 26) return;
-    const int32_t slot = blockIdx.y;
+    const int32_t slot = slots[blockIdx.y];
     const int64_t id = t / 26;
     const int k = (int)(t - id * 26);
     const int32_t end = D.ctl[slot].end;
@@ -1692,7 +1695,7 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
     const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
     unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
-    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
     const int k = lane < 26 ? lane : 25;
     int dx, dy, dz;
@@ -1810,7 +1813,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    const float *heur = D.heur + (int64_t)slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
     int32_t r_node = 0;
     float r_L = 0.f;

@@ -55,6 +55,8 @@ struct WaSlotCtl {
     float clean[2];
     uint32_t evap_base;     // evaporations applied to the field before generation 0 of the current solve (carried across solves)
     int32_t tabu_gen;       // generation in which the best path last changed: the replay-table rows of that generation rebuild besttabu[]
+    int32_t heur_slot;      // whose heuristic field this search reads: searches of one wa_acs_begin with the same end point share one
+    int32_t pad_;
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index

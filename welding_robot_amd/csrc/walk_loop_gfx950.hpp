@@ -101,6 +101,7 @@
 #define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_NONE)
 #define WA_ASM_STEP_REJ(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_WATCH)
 #define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_NONE)
+#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_WATCH)
 #define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ)                                  \
     WA_ASM_WARM_ADDR                                              /* (s40 = cur * 24 since the previous step's tail) */ \
     WA_ASM_STAMP(72)                                                                                              \
@@ -288,9 +289,46 @@
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
 
+// the lazy-field loop as a statement (STEP = WA_ASM_STEP_LAZY or WA_ASM_STEP_LAZY_REJ; REJINIT / REJEXITS = the rejoin watch's
+// set-up and hand-back stubs, empty without it; `mark` is passed either way)
+#define WA_ASM_RUN_LAZY(STEP, REJINIT, REJEXITS)                                                                  \
+    asm volatile(                                                                                                 \
+        WA_ASM_PROLOGUE                                                                                           \
+        "ds_read_b32 v99, %[lc] offset:3328\n"        /* stamp offset of this lane's neighbour */                 \
+        "ds_read_b32 v94, %[lc] offset:3584\n"        /* lanes 0..2: clean value, evap_now + 1, rho; 3, 4: version, hold-off */ \
+        "v_mov_b32 v96, %[sio]\n"                                                                                 \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                  \
+        "v_readlane_b32 s33, v94, 0\n"                                                                            \
+        "v_readlane_b32 s34, v94, 1\n"                                                                            \
+        "v_readlane_b32 s35, v94, 2\n"                                                                            \
+        REJINIT                                                                                                   \
+        "s_lshl_b32 s46, %[cur], 2\n"                                                                             \
+        "v_add_u32 v98, s46, v99\n"                                                                               \
+        "global_load_dword v97, v98, %[stamp]\n"                                                                  \
+        WA_ASM_STAMPS_INIT                                                                                        \
+        "Lwa_top%=:\n"                                                                                            \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "a")                                                       \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "b")                                                       \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "c")                                                       \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "d")                                                       \
+        "s_branch Lwa_top%=\n"                                                                                    \
+        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d") \
+        "Lwa_rare_a%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "0")                             \
+        "Lwa_rare_b%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "1")                             \
+        "Lwa_rare_c%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "2")                             \
+        "Lwa_rare_d%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "3")                             \
+        REJEXITS                                                                                                  \
+        WA_ASM_TAIL                                                                                               \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), \
+          [sio] "+v"(pd)                                                                                          \
+        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b), [markb] "s"(mark) \
+        : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
+
 // VARIANT 0: dense field.  1 (LAZY): the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the
 // slot's stamp array, clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far.
-// 2: dense field + rejoin watch: `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
+// 2: dense field + rejoin watch (3: lazy field + rejoin watch): `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
 // st.reason = 4 when the loop handed back because the ant stood on the best path one step ago.
 template <int VARIANT>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
@@ -301,7 +339,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                                                  int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg,
                                                  const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0)
 {
-    constexpr bool LAZY = VARIANT == 1, REJOIN = VARIANT == 2;
+    constexpr bool LAZY = VARIANT == 1 || VARIANT == 3, REJOIN = VARIANT == 2 || VARIANT == 3;
     const int lane = threadIdx.x;
     const int j = lane >> 3, pos = lane & 7;
     const int k2 = pos < 6 ? 5 - pos : 0;   // edge this lane evaluates; positions 6,7 of a group are padding (never admissible)
@@ -325,9 +363,11 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         lc[6 * 64 + lane] = (table + lane) * 4;                                      // this lane's dummy slot
         if (LAZY) {
             lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
-            lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : __float_as_int(R.rho);
         }
-        if (REJOIN) lc[14 * 64 + lane] = lane == 0 ? (int32_t)ver : hold_off;
+        // column 14, lanes 0..2: clean value, evap_now + 1, rho (lazy field); lanes 3, 4: best-path version, hold-off (rejoin watch)
+        if (LAZY || REJOIN)
+            lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
+                                 : lane == 3 ? (int32_t)ver : hold_off;
     }
     const int32_t lcaddr = (table + 64 + lane) * 4;
     int32_t cur = st.cur, len = st.len, g8 = 0;
@@ -349,14 +389,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
         int32_t code;
-        if (REJOIN) {
+        if (REJOIN && !LAZY) {
             asm volatile(
                 WA_ASM_PROLOGUE
-                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 0, 1: best-path version, hold-off
+                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 3, 4: best-path version, hold-off
                 "s_mov_b32 s78, -1\n"                         // (no voxel looked up yet: a version number never gets that far)
                 "s_waitcnt lgkmcnt(0)\n"
-                "v_readlane_b32 s80, v94, 0\n"
-                "v_readlane_b32 s81, v94, 1\n"
+                "v_readlane_b32 s80, v94, 3\n"
+                "v_readlane_b32 s81, v94, 4\n"
                 "Lwa_top%=:\n"
                 WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a")
                 WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b")
@@ -387,38 +427,12 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                 : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
                   [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
                 : WA_ASM_CLOBBERS);
+        } else if (REJOIN) {
+            WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ,
+                            "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n",
+                            WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d"))
         } else {
-            asm volatile(
-                WA_ASM_PROLOGUE
-                "ds_read_b32 v99, %[lc] offset:3328\n"        // stamp offset of this lane's neighbour
-                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 0..2: clean value, evap_now + 1, rho
-                "v_mov_b32 v96, %[sio]\n"
-                "s_waitcnt lgkmcnt(0)\n"
-                "v_readlane_b32 s33, v94, 0\n"
-                "v_readlane_b32 s34, v94, 1\n"
-                "v_readlane_b32 s35, v94, 2\n"
-                "s_lshl_b32 s46, %[cur], 2\n"
-                "v_add_u32 v98, s46, v99\n"
-                "global_load_dword v97, v98, %[stamp]\n"
-                WA_ASM_STAMPS_INIT
-                "Lwa_top%=:\n"
-                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "a")
-                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "b")
-                WA_ASM_STEP_LAZY("v71", "v72", "v96", "v73", "v74", "v97", "c")
-                WA_ASM_STEP_LAZY("v73", "v74", "v97", "v71", "v72", "v96", "d")
-                "s_branch Lwa_top%=\n"
-                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-                WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d")
-                "Lwa_rare_a%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "0")
-                "Lwa_rare_b%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "1")
-                "Lwa_rare_c%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "2")
-                "Lwa_rare_d%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "3")
-                WA_ASM_TAIL
-                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock),
-                  [sio] "+v"(pd)
-                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b)
-                : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", WA_ASM_CLOBBERS);
+            WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, "", "")
         }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {

@@ -69,6 +69,9 @@ struct wa_acs {
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
+    int32_t *d_hslot, *d_hlist;         // per slot: whose heuristic field it reads / the slots whose field wa_acs_begin computes
+    std::vector<long long> heur_end;    // end point the heuristic field of each slot currently holds (-1: none)
+    std::vector<float> heur_beta;
     // profiling
     bool prof;
     int32_t prof_every;

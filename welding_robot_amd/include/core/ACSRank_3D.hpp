@@ -202,6 +202,10 @@ public:
             const int batch = rng_mode == WA_RNG_REF ? 1 : slots;
             std::vector<size_t> mine;
             for (size_t k = (size_t)d; k < pairs.size(); k += (size_t)D) mine.push_back(k);
+            // searches of one batch that end in the same point share one heuristic field on the device (wa_acs_begin): run them
+            // side by side.  The order does not change any result (every search draws from the stream of its global pair index).
+            if (rng_mode != WA_RNG_REF)
+                std::stable_sort(mine.begin(), mine.end(), [&](size_t a, size_t b) { return pairs[a].second < pairs[b].second; });
             for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
                 int nb = (int)std::min<size_t>(batch, mine.size() - b0);
                 std::vector<int64_t> s0(nb), e0(nb);
