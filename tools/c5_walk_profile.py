@@ -2,7 +2,7 @@
 """BASELINE config C5, one batch of pair searches (96 slots x 24 ants on 256^3, lazy evaporation): kernel time per
 generation range (diagnostic) -- where do the 150 generations of a batch spend their time?
 
-    python tools/c5_walk_profile.py [grid] [points] [slots] [generations]
+    python tools/c5_walk_profile.py [grid] [points] [slots] [generations] [batch]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,9 @@ ctx = api.Context(0)
 free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
 grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
 pts = synth.synth_weld_points(free, n, P, seed=7)
-pairs = [(i, j) for i in range(P) for j in range(i + 1, P)][:slots]
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 10          # which batch of the end-point-ordered list (as plan_batch.py runs them)
+allp = sorted([(i, j) for i in range(P) for j in range(i + 1, P)], key=lambda t: (t[1], t[0]))
+pairs = allp[B * slots:(B + 1) * slots]
 s = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=24, lazy=True)
 p = api.default_params(max_iteration=G, predict=float(24 / 0.35), rng_mode=api.RNG_DEV, seed=7)
 s.begin(p, [pts[a] for a, b in pairs], [pts[b] for a, b in pairs], streams=list(range(len(pairs))))
