@@ -743,7 +743,9 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
             if (st.done || st.reason != 4) break;
             int32_t gained = 0;
-            const int32_t q = mark[st.cur] == best_ver ? bpos[st.cur] : -1;
+            const uint32_t mk = mark[st.cur];
+            const int32_t ps = bpos[st.cur];                      // (fetched beside the stamp, meaningful only under it)
+            const int32_t q = mk == best_ver ? ps : -1;
             if (q >= 0 && q < rlen - 1 && !(walk_flags & 4)) {
                 int32_t room = spill_at - st.len;                 // nodes the tabu hash / the path may still take
                 if ((int32_t)D.path_cap - st.len < room) room = (int32_t)D.path_cap - st.len;
@@ -757,22 +759,27 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                     uint32_t hh = ((uint32_t)key * 2654435761u) >> T.shift;
                     while (atomicCAS(&tab[hh], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) hh = (hh + 1) & T.mask;
                 }
-                __threadfence_block();
                 __builtin_amdgcn_wave_barrier();
+                if (gained > 0) {
+                    // the words of the ant's incomplete 64-word block stay in a register across the re-entry (lane i = word i of the
+                    // block): what was there before the commit, then the committed words -- all of it when the commit crossed a boundary
+                    const int32_t old_len = st.len, new_len = st.len + gained;
+                    const int32_t wi = (new_len & ~63) + lane;
+                    int32_t pb = 0;
+                    if (lane < (new_len & 63)) pb = wi >= old_len ? bpath[q + 1 + (wi - old_len)] : st.pbuf;
+                    st.pbuf = pb;
+                }
                 st.len += gained;
-                if (gained > 0) st.pbuf_valid = false;
                 st.step = (uint32_t)(st.len - 1);
                 st.cur = bpath[stop] & (int32_t)WA_ID_MASK;
-                st.L = D.ltab[st.len - 1];
-                if (kind == 2) { st.done = true; break; }                       // arrived over the rest of the best path
+                if (kind == 2) { st.L = D.ltab[st.len - 1]; st.done = true; break; }   // arrived over the rest of the best path (:78)
                 if (kind == 1) { st.L = INFINITY; st.done = true; break; }      // no candidate at best[stop] (:162-166, :191-192)
             }
             if (gained > 0) { backoff = 1; hold = 1; }
             else { hold = backoff; backoff = backoff < 32 ? backoff * 2 : 32; }   // the table does not apply here: walk on before asking again
             if (st.len >= fast_limit) break;
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it
     } else if (st.len < fast_limit && use_asm)
         wa_walk_fast_asm<SPARSE ? 1 : 0>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);

@@ -458,8 +458,10 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
 #if defined(WA_ASM_STAMPS)
     if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
 #endif
-    float L = exit_code == 1 ? INFINITY : ltab[len - 1];   // :78, one add of `precision` per step taken
     st.done = exit_code != 3 && exit_code != 4;
+    // :78, one add of `precision` per step taken (table).  A walk handed back by the rejoin watch does not need it yet: the
+    // load would sit on the path of every re-entry
+    float L = exit_code == 1 ? INFINITY : exit_code == 4 ? 0.f : ltab[len - 1];
     if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
         L = INFINITY;
