@@ -643,7 +643,7 @@ __device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const
     }
 }
 
-template <int MODE, bool ALPHA1, bool SPARSE>
+template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
@@ -738,7 +738,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         const float *RT = D.rtab + (int64_t)slot * D.path_cap * 8;
         int32_t hold = ((walk_flags >> 8) & 0xffff) ? ((walk_flags >> 8) & 0xffff) : 1, backoff = 1;
         for (;;) {
-            wa_walk_fast_asm<SPARSE ? 3 : 2>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+            wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                              D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, (walk_flags & 8) ? 0u : best_ver, hold);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
             if (st.done || st.reason != 4) break;
@@ -781,7 +781,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         }
         if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it
     } else if (st.len < fast_limit && use_asm)
-        wa_walk_fast_asm<SPARSE ? 1 : 0>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+        wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
@@ -932,7 +932,9 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
-template <bool ALPHA1, bool SPARSE>
+// WARM: the hand-scheduled loop touches the records two hops ahead of the ant (pays while a search has the GPU to itself, costs
+// when many searches saturate it: see walk_loop_gfx950.hpp)
+template <bool ALPHA1, bool SPARSE, bool WARM = true>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     // the rejoin watch pays once the colony has settled on the best path (it costs a failed attempt every few steps while the
     // ants still explore): it is switched on when that path has not changed for a number of generations
     if (gen - c->tabu_gen < ((walk_flags >> 24) & 127)) walk_flags &= ~2;
-    wa_walk_one<1, ALPHA1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
+    wa_walk_one<1, ALPHA1, SPARSE, WARM>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver);
 }
 

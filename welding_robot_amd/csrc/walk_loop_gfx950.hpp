@@ -22,18 +22,21 @@
 #define WA_WALK_LDS_EXTRA 4096   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants (+ 6 x 64 diagnostic sums)
 #define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
 #define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
-// experiment switches (timing studies only; the product build defines none of them)
-#if defined(WA_ASM_NOWARM)
-#define WA_ASM_WARM_ADDR ""
-#define WA_ASM_WARM0 "s_nop 0\n"
-#define WA_ASM_WARM1 "s_nop 0\n"
-#define WA_ASM_VMWAIT "s_waitcnt vmcnt(2)\n"
-#else
-#define WA_ASM_WARM_ADDR "v_add_u32 v83, s40, v66\n"
-#define WA_ASM_WARM0 "global_load_dwordx4 v[86:89], v83, %[pher]\n"
-#define WA_ASM_WARM1 "global_load_dwordx4 v[90:93], v83, %[heur]\n"
-#define WA_ASM_VMWAIT "s_waitcnt vmcnt(4)\n"
-#endif
+// The records two hops away are touched with two 16-byte loads nobody waits for (W = SELF), or not at all (W = NONE):
+//   SELF pays when ONE search owns the GPU (a walk block per CU, a lone wave per SIMD): the touches put the next records into the
+//        CU's L1 / the XCD's L2 before the real loads ask for them (generation 0-10 walk launches at C3: 186 vs 200 us);
+//   NONE pays when many searches saturate it (BASELINE config C5: 2 304 walk blocks): the touches are two thirds of the cache
+//        lines a step requests, the walk is then bound by L2 / address-pipeline throughput, not by latency (C5: 0.99 -> 0.87 s).
+#define WA_ASM_WARM_ADDR_SELF "v_add_u32 v83, s40, v66\n"
+#define WA_ASM_WARM0_SELF "global_load_dwordx4 v[86:89], v83, %[pher]\n"
+#define WA_ASM_WARM1_SELF "global_load_dwordx4 v[90:93], v83, %[heur]\n"
+#define WA_ASM_VMWAIT_SELF "s_waitcnt vmcnt(4)\n"
+#define WA_ASM_VMWAIT_LAZY_SELF "s_waitcnt vmcnt(5)\n"          /* (one more load per step: the stamp) */
+#define WA_ASM_WARM_ADDR_NONE ""
+#define WA_ASM_WARM0_NONE "s_nop 0\n"                           /* (keeps the compares four instructions away from their scalar consumers) */
+#define WA_ASM_WARM1_NONE "s_nop 0\n"
+#define WA_ASM_VMWAIT_NONE "s_waitcnt vmcnt(2)\n"
+#define WA_ASM_VMWAIT_LAZY_NONE "s_waitcnt vmcnt(3)\n"
 // -DWA_ASM_STAMPS (diagnostic builds, tools/walk_stamps_asm.py): s_memtime at six points of the step, differences summed in
 // s72..s77 (s70 = previous stamp); each stamp drains LDS and costs ~40 cycles: read the shares, not the totals
 #if defined(WA_ASM_STAMPS)
@@ -98,12 +101,12 @@
     "v_mov_b32 %[hio], " CH "\n"                                                                                  \
     "s_mov_b32 %[code], 4\n"                                                                                      \
     "s_branch Lwa_out%=\n"
-#define WA_ASM_STEP(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_NONE)
-#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT, WA_ASM_REJ_WATCH)
-#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_NONE)
-#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, "s_waitcnt vmcnt(5)\n", WA_ASM_REJ_WATCH)
-#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ)                                  \
-    WA_ASM_WARM_ADDR                                              /* (s40 = cur * 24 since the previous step's tail) */ \
+#define WA_ASM_STEP(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_NONE, W)
+#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_WATCH, W)
+#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_NONE, W)
+#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_WATCH, W)
+#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ, W)                                \
+    WA_ASM_WARM_ADDR_##W                                          /* (s40 = cur * 24 since the previous step's tail) */ \
     WA_ASM_STAMP(72)                                                                                              \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
     WA_ASM_STAMP(73)                                                                                              \
@@ -115,8 +118,8 @@
     WA_ASM_STAMP(74)                                                                                              \
     "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
     INFO(CP, CH, CS, X)                                                                                           \
-    WA_ASM_WARM0                                                  /* records two hops away: touched, never waited for */ \
-    WA_ASM_WARM1                                                                                                  \
+    WA_ASM_WARM0_##W                                              /* records two hops away: touched, never waited for */ \
+    WA_ASM_WARM1_##W                                                                                              \
     INFO2(X)                                                                                                      \
     "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
     "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
@@ -289,9 +292,48 @@
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
 
+#define WA_ASM_REJ_INIT "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n"
+#define WA_ASM_REJ_EXITS WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
+// the two dense loops as statements (W = SELF | NONE: the touch loads, see above)
+#define WA_ASM_RUN_DENSE(W)                                                                                       \
+    asm volatile(                                                                                                 \
+        WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT                                                                        \
+        "Lwa_top%=:\n"                                                                                            \
+        WA_ASM_STEP("v71", "v72", "v73", "v74", "a", W)                                                           \
+        WA_ASM_STEP("v73", "v74", "v71", "v72", "b", W)                                                           \
+        WA_ASM_STEP("v71", "v72", "v73", "v74", "c", W)                                                           \
+        WA_ASM_STEP("v73", "v74", "v71", "v72", "d", W)                                                           \
+        "s_branch Lwa_top%=\n"                                                                                    \
+        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
+        WA_ASM_TAIL                                                                                               \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
+        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))                    \
+        : WA_ASM_CLOBBERS);
+#define WA_ASM_RUN_REJ(W)                                                                                         \
+    asm volatile(                                                                                                 \
+        WA_ASM_PROLOGUE                                                                                           \
+        "ds_read_b32 v94, %[lc] offset:3584\n"        /* lanes 3, 4: best-path version, hold-off */               \
+        "s_waitcnt lgkmcnt(0)\n"                                                                                  \
+        WA_ASM_REJ_INIT                                                                                           \
+        "Lwa_top%=:\n"                                                                                            \
+        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a", W)                                                       \
+        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b", W)                                                       \
+        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "c", W)                                                       \
+        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "d", W)                                                       \
+        "s_branch Lwa_top%=\n"                                                                                    \
+        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
+        WA_ASM_REJ_EXITS                                                                                          \
+        WA_ASM_TAIL                                                                                               \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
+        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark)  \
+        : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 // the lazy-field loop as a statement (STEP = WA_ASM_STEP_LAZY or WA_ASM_STEP_LAZY_REJ; REJINIT / REJEXITS = the rejoin watch's
 // set-up and hand-back stubs, empty without it; `mark` is passed either way)
-#define WA_ASM_RUN_LAZY(STEP, REJINIT, REJEXITS)                                                                  \
+#define WA_ASM_RUN_LAZY(STEP, W, REJINIT, REJEXITS)                                                                 \
     asm volatile(                                                                                                 \
         WA_ASM_PROLOGUE                                                                                           \
         "ds_read_b32 v99, %[lc] offset:3328\n"        /* stamp offset of this lane's neighbour */                 \
@@ -307,10 +349,10 @@
         "global_load_dword v97, v98, %[stamp]\n"                                                                  \
         WA_ASM_STAMPS_INIT                                                                                        \
         "Lwa_top%=:\n"                                                                                            \
-        STEP("v71", "v72", "v96", "v73", "v74", "v97", "a")                                                       \
-        STEP("v73", "v74", "v97", "v71", "v72", "v96", "b")                                                       \
-        STEP("v71", "v72", "v96", "v73", "v74", "v97", "c")                                                       \
-        STEP("v73", "v74", "v97", "v71", "v72", "v96", "d")                                                       \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "a", W)                                                     \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "b", W)                                                     \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "c", W)                                                     \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "d", W)                                                     \
         "s_branch Lwa_top%=\n"                                                                                    \
         WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
         WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d") \
@@ -330,7 +372,7 @@
 // slot's stamp array, clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far.
 // 2: dense field + rejoin watch (3: lazy field + rejoin watch): `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
 // st.reason = 4 when the loop handed back because the ant stood on the best path one step ago.
-template <int VARIANT>
+template <int VARIANT, bool WARM = true>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
                                                  int32_t *path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
@@ -390,49 +432,13 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
         int32_t code;
         if (REJOIN && !LAZY) {
-            asm volatile(
-                WA_ASM_PROLOGUE
-                "ds_read_b32 v94, %[lc] offset:3584\n"        // lanes 3, 4: best-path version, hold-off
-                "s_mov_b32 s78, -1\n"                         // (no voxel looked up yet: a version number never gets that far)
-                "s_waitcnt lgkmcnt(0)\n"
-                "v_readlane_b32 s80, v94, 3\n"
-                "v_readlane_b32 s81, v94, 4\n"
-                "Lwa_top%=:\n"
-                WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a")
-                WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b")
-                WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "c")
-                WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "d")
-                "s_branch Lwa_top%=\n"
-                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-                WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
-                WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
-                WA_ASM_TAIL
-                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
-                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark)
-                : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
+            if (WARM) { WA_ASM_RUN_REJ(SELF) } else { WA_ASM_RUN_REJ(NONE) }
         } else if (!LAZY) {
-            asm volatile(
-                WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT
-                "Lwa_top%=:\n"
-                WA_ASM_STEP("v71", "v72", "v73", "v74", "a")
-                WA_ASM_STEP("v73", "v74", "v71", "v72", "b")
-                WA_ASM_STEP("v71", "v72", "v73", "v74", "c")
-                WA_ASM_STEP("v73", "v74", "v71", "v72", "d")
-                "s_branch Lwa_top%=\n"
-                WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")
-                WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3")
-                WA_ASM_TAIL
-                : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock)
-                : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path),
-                  [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))
-                : WA_ASM_CLOBBERS);
+            if (WARM) { WA_ASM_RUN_DENSE(SELF) } else { WA_ASM_RUN_DENSE(NONE) }
         } else if (REJOIN) {
-            WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ,
-                            "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n",
-                            WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d"))
+            if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, SELF, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
         } else {
-            WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, "", "")
+            if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, SELF, "", "") } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "") }
         }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {
