@@ -648,11 +648,11 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
                                             int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags,
-                                            uint32_t best_ver = 0)
+                                            uint32_t best_ver, int32_t heur_slot)
 {
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
+    const float *heur = D.heur + (int64_t)heur_slot * D.pher_stride;   // (the caller read it with the rest of the control block)
     const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
     const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
     int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     // ants still explore): it is switched on when that path has not changed for a number of generations
     if (gen - c->tabu_gen < ((walk_flags >> 24) & 127)) walk_flags &= ~2;
     wa_walk_one<1, ALPHA1, SPARSE, WARM>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
-                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver);
+                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -970,9 +970,9 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t r[31];
     for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
     int32_t f = D.rng->f, b = D.rng->b;
-    const int32_t start = c->start, end = c->end;
+    const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
     for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0);
+        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
@@ -1995,7 +1995,7 @@ __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash
     int32_t r[31];
     for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
     int32_t f = D.rng->f, b = D.rng->b;
-    const int32_t start = c->start, end = c->end;
+    const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
     for (int32_t ant = 0; ant < colony; ant++)
         wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0);
     if (threadIdx.x == 0) {
