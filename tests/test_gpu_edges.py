@@ -230,3 +230,31 @@ def test_searches_with_the_same_end_point_share_one_heuristic_field(ctx):
             assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), (b, q)
             assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), (b, q)
     s.close()
+
+
+def test_heuristic_field_pool_grows_and_recycles(ctx):
+    """The pool starts with four fields: a batch with six distinct end points grows it (keeping what it holds), later batches
+    recycle the fields that the current batch does not use, oldest first.  Every search against its own oracle run."""
+    og = box_grid(13, 11, 10, occ_prob=0.08, seed=4)
+    n = 13 * 11 * 10
+    free = np.nonzero(og.free)[0]
+    pts = [int(free[i]) for i in (0, 7, 50, 200, 400, 700, 900, len(free) - 1)]
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, n_slots=6, max_colony=8)
+    batches = [
+        ([0, 1, 2], [7, 7, 6]),                    # two end points
+        ([0, 1, 2, 3, 4, 6], [7, 6, 5, 4, 3, 2]),  # six: the pool grows from four to six fields, 7 and 6 are kept
+        ([1, 2, 3, 4], [0, 0, 1, 7]),              # new end points recycle the oldest fields; 7 is still there
+        ([5, 4, 3, 2, 1, 0], [6, 5, 4, 3, 2, 1]),
+    ]
+    for b, (st, en) in enumerate(batches):
+        p = api.default_params(max_iteration=7, predict=25.0, fixed_colony=8, rng_mode=api.RNG_DEV, seed=90 + b)
+        s.init_pheromone(1.0)
+        s.solve(p, [pts[i] for i in st], [pts[i] for i in en], streams=list(range(len(st))))
+        for q in range(len(st)):
+            a = O.Acs(og)
+            tr = a.solve(pts[st[q]], pts[en[q]], 7, 25.0, fixed_colony=8, mode=O.DEV, seed=90 + b, stream=q)
+            t = s.trace(q)
+            assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), (b, q)
+            assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), (b, q)
+    s.close()

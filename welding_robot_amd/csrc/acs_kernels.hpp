@@ -92,14 +92,15 @@ __global__ __launch_bounds__(256) void k_init_pheromone(WaAcsDev D, int32_t slot
 }
 
 // ------------------------------------------------------------------ heuristic field
-// (1 + beta*cos) of :151-154 is a function of the voxel, the edge and the END point only: wa_acs_begin computes one field per
-// distinct end point of its batch (`slots` = the slots that own one) and every search reads the field ctl.heur_slot names
-__global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta, const int32_t *slots)
+// (1 + beta*cos) of :151-154 is a function of the voxel, the edge and the END point only: the fields live in a pool,
+// wa_acs_begin computes one per distinct end point of its batch that the pool does not hold yet (`fields` / `ends` = pool
+// index and end point of each field to compute) and every search reads the field ctl.heur_slot names
+__global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta, const int32_t *fields, const int32_t *ends)
 {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= D.d.n) return;
-    int32_t slot = slots[blockIdx.y];
-    int32_t end = D.ctl[slot].end;
+    int32_t slot = fields[blockIdx.y];
+    int32_t end = ends[blockIdx.y];
     int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
     int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
     float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
@@ -1635,14 +1636,14 @@ __global__ __launch_bounds__(256) void k_init_pheromone26(WaAcsDev D, int32_t sl
     D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
 }
 
-__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta, const int32_t *slots)
+__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta, const int32_t *fields, const int32_t *ends)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= D.d.n * 26) return;
-    const int32_t slot = slots[blockIdx.y];
+    const int32_t slot = fields[blockIdx.y];
     const int64_t id = t / 26;
     const int k = (int)(t - id * 26);
-    const int32_t end = D.ctl[slot].end;
+    const int32_t end = ends[blockIdx.y];
     const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
     const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
     int dx, dy, dz;

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -70,9 +71,13 @@ struct wa_acs {
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
-    int32_t *d_hslot, *d_hlist;         // per slot: whose heuristic field it reads / the slots whose field wa_acs_begin computes
-    std::vector<long long> heur_end;    // end point the heuristic field of each slot currently holds (-1: none)
-    std::vector<float> heur_beta;
+    int32_t *d_hslot, *d_hlist, *d_hends;   // per search: the heuristic field it reads / the fields wa_acs_begin computes and their end points
+    int32_t heur_fields;                // fields in the pool (heur_alloc): grows on demand, at most one per slot
+    size_t heur_guard;                  // floats of guard band around the pool
+    std::vector<long long> heur_end;    // per field: the end point it holds (-1: none), the beta it was computed with,
+    std::vector<float> heur_beta;       // ... and the last wa_acs_begin that used it (oldest goes first)
+    std::vector<long long> heur_used;
+    long long heur_batch;
     // profiling
     bool prof;
     int32_t prof_every;
