@@ -118,6 +118,30 @@ def sweep_roofline(ctx, n, repeats=64):
             "achieved": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
 
 
+def walk_step_extra(solver, p, ids, wl, generations=12):
+    """What the exploratory generations are made of, measured after the timed region on a fresh identical search: a walk
+    launch lasts as long as its slowest ant, so launch time / the longest walk of the generation = the time of one
+    general step of a lone wavefront (61 instructions at ~4.3 cycles of issue each + load issue + stalls).
+    `issue_floor_ns` is what 61 instructions alone would take at the measured 2.39 GHz shader clock -- the bound this
+    latency-bound kernel can be held against (it is neither an HBM nor an MFMA kernel)."""
+    import numpy as np
+    solver.init_pheromone(1.0)
+    solver.begin(p, ids[0], ids[1], streams=[wl["stream"]])
+    ns = []
+    for g in range(generations):
+        solver.profile(True, 1)
+        solver.run(1)
+        pr = solver.profile_read()
+        _, lens = solver.ants()
+        ns.append(pr["walk"]["ms"] * 1e6 / max(int(lens.max()) - 1, 1))
+    solver.profile(False, 1)
+    step = float(np.median(ns))
+    floor = 61 * 4.3 / 2.39
+    return {"ns_per_step_of_the_longest_walk": step, "generations_sampled": generations, "instructions_per_step": 61,
+            "issue_floor_ns": floor, "frac_of_issue_floor": floor / step if step > 0 else 0.0,
+            "source": "walk launch time / max(ant steps) per generation; ISA in profiles/r02/walk_loop_isa.txt, issue rates in profiles/r02/issue_rates.txt"}
+
+
 def pair_planning_extra(ctx, grid, free, n):
     """Secondary, informational: BASELINE config C5's shape on the bench grid -- all pair searches between 16 weld
     points (120 pairs x 150 generations, 24 ants each, 32 concurrent slots) with the dense sweep and with lazy
@@ -303,6 +327,8 @@ def main():
             solver.sync()
             gpu_first_ms = (time.perf_counter() - t1) * 1e3
             out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl))
+        if world == 1:
+            out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
         print(json.dumps(out), flush=True)
