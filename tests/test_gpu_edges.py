@@ -258,3 +258,34 @@ def test_heuristic_field_pool_grows_and_recycles(ctx):
             assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), (b, q)
             assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), (b, q)
     s.close()
+
+
+def test_byte_rank_masks_equal_u64_rank_masks(ctx):
+    """A solver whose colonies never exceed 35 ants (at most 8 depositing ranks, ACSRank_3D.hpp:200) keeps its deposit rank
+    masks in one byte per edge; WA_MASK_U64=1 keeps the u64 masks.  Dense and lazy, 8 ranks exactly (35 ants), shared words
+    (edges of one voxel sit in the same 32-bit word the marks OR into)."""
+    og = box_grid(20, 16, 12, occ_prob=0.08, seed=12)
+    og.free[0] = og.free[-1] = 1
+    n = 20 * 16 * 12
+    res = {}
+    for lazy in (False, True):
+        for wide in ("0", "1"):
+            os.environ["WA_MASK_U64"] = wide
+            try:
+                dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+                s = api.AcsSolver(ctx, dg, n_slots=2, max_colony=35, lazy=lazy)
+                p = api.default_params(max_iteration=30, predict=100.0, fixed_colony=35, rng_mode=api.RNG_DEV, seed=3)
+                s.init_pheromone(1.0)
+                s.solve(p, [0, n - 1], [n - 1, 0], streams=[4, 9])
+                res[(lazy, wide)] = [(s.trace(q), s.pheromone(q)) for q in range(2)]
+                s.close()
+            finally:
+                del os.environ["WA_MASK_U64"]
+    a = O.Acs(og)
+    tr = a.solve(0, n - 1, 30, 100.0, fixed_colony=35, mode=O.DEV, seed=3, stream=4)
+    for key, slots in res.items():
+        t, ph = slots[0]
+        assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), key
+        assert np.array_equal(bits(ph), bits(a.pheromone())), key
+        for q in range(2):
+            assert np.array_equal(bits(slots[q][1]), bits(res[(False, "1")][q][1])), (key, q)

@@ -19,7 +19,8 @@ struct WaAcsDev {
     const float *cx, *cy, *cz;
     const uint8_t *occ;            // free_[id]
     float *pher, *heur;            // [slot][pher_stride]
-    unsigned long long *mask;      // [slot][pher_stride]
+    unsigned long long *mask;      // [slot][pher_stride]  deposit rank masks, one bit per depositing rank of the pass (<= 64) ...
+    uint8_t *mask8;                // ... or, when at most 8 ranks can ever deposit (max_colony <= 35), one BYTE per edge (mask == null)
     uint32_t *bestmark;            // [slot][n]
     int32_t *bestpos;              // [slot][n]  index of a marked voxel on the best path
     uint8_t *besttabu;             // [slot][path_cap] bit k: neighbour k of best[i] lies on the prefix best[0..i]
@@ -58,6 +59,31 @@ struct WaAcsDev {
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
 };
+
+// rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
+struct WaMaskRef {
+    unsigned long long *w;
+    uint8_t *b;
+};
+__device__ __forceinline__ WaMaskRef wa_mask_of(const WaAcsDev &D, int32_t slot)
+{
+    WaMaskRef m;
+    m.w = D.mask ? D.mask + (int64_t)slot * D.pher_stride : nullptr;
+    m.b = D.mask8 ? D.mask8 + (int64_t)slot * D.pher_stride : nullptr;
+    return m;
+}
+__device__ __forceinline__ void wa_mask_or(const WaMaskRef &m, int64_t e, int bit)
+{
+    if (m.w) atomicOr(&m.w[e], 1ULL << bit);
+    else atomicOr(reinterpret_cast<unsigned int *>(m.b + (e & ~(int64_t)3)), (1u << bit) << (8 * (int)(e & 3)));
+}
+__device__ __forceinline__ unsigned long long wa_mask_get(const WaMaskRef &m, int64_t e) { return m.w ? m.w[e] : (unsigned long long)m.b[e]; }
+__device__ __forceinline__ void wa_mask_clear(const WaMaskRef &m, int64_t e)
+{
+    if (m.w) m.w[e] = 0;
+    else m.b[e] = 0;
+}
+
 
 // path word = voxel id | (edge index taken to arrive << SHIFT)
 template <int NB> struct WaNbT;
@@ -156,7 +182,9 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 
+#ifndef WA_LAZY_PERIOD
 #define WA_LAZY_PERIOD 16
+#endif
 // stored value -> value after `lag` more evaporations (:270, one rounding per multiplication like the sweep)
 __device__ __forceinline__ float wa_catch_up(float v, uint32_t lag, float rho)
 {
@@ -833,7 +861,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
     // that block's dependent gathers used to outlast the whole evaporation sweep in exploratory generations
     const bool rebuild = ctl->tabu_gen + 1 == ctl->gen;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    const WaMaskRef mask = wa_mask_of(D, slot);
     const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * 8;
     const int32_t dk = wa_delta(kk, D.d.nx, D.d.nxy);
@@ -856,7 +884,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
             const uint32_t stv = stamp[v];
             p = stv == 0 ? copysignf(clean_now, p) : copysignf(wa_catch_up(fabsf(p), evap_tab + 1u - stv, R.rho), p);
         }
-        unsigned long long m = apply_here ? mask[e] : 0ULL;
+        unsigned long long m = apply_here ? wa_mask_get(mask, e) : 0ULL;
         int32_t nbid = v + dk;
         nbid = nbid < 0 ? 0 : nbid > last_id ? last_id : nbid;       // (an out-of-bounds edge is inadmissible by its sign bit whatever is found here)
         const uint32_t mk = (apply_here || rebuild) ? mark[nbid] : 0u;
@@ -880,7 +908,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
                     p += s_dep[b] + bonus;
                 }
                 pher[e] = p;
-                mask[e] = 0;
+                wa_mask_clear(mask, e);
             }
             // in bounds and free (:148), and not on the prefix best[0..i] (:145-146)
             adm = (__float_as_uint(p) >> 31) == 0 && !((bt >> k2) & 1u);
@@ -1405,14 +1433,14 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const int32_t a = s_perm[o - 1];
     const int32_t len = antLen[a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
-    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    const WaMaskRef mask = wa_mask_of(D, slot);
     float *ph = dst_base + (int64_t)slot * D.pher_stride;
     const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
     for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += (blockDim.x << WA_MARK_SPLIT_LOG2)) {
         int32_t w = path[i];
         int32_t v = path[i - 1] & WaNbT<NB>::IDM;
         int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
-        atomicOr(&mask[e], 1ULL << bit);
+        wa_mask_or(mask, e, bit);
         if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
             uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
             const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;
@@ -1461,12 +1489,12 @@ __global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
     const int32_t a = D.perm[(int64_t)slot * D.max_colony + o - 1];
     const int32_t len = D.antLen[(int64_t)slot * D.max_colony + a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
-    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    const WaMaskRef mask = wa_mask_of(D, slot);
     for (int32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         int32_t w = path[i];
         int32_t v = path[i - 1] & WaNbT<NB>::IDM;
         int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
-        atomicOr(&mask[e], 1ULL << bit);
+        wa_mask_or(mask, e, bit);
     }
 }
 // Body of the apply pass for rank bit `bit` of chunk `base`, x-block `bx` of `nbx`.  skip_best_src: edges that
@@ -1495,7 +1523,7 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
     const int32_t len = D.antLen[(int64_t)slot * C + a];
     int32_t w = i0 < D.path_cap ? path[i0] : 0, pv = i0 < D.path_cap ? path[i0 - 1] : 0;
     __syncthreads();
-    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    const WaMaskRef mask = wa_mask_of(D, slot);
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
     for (int32_t i = i0; i < len; i += nbx * (int32_t)blockDim.x) {
@@ -1504,7 +1532,7 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
         const int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
         // level 3: four independent loads
         const uint32_t mv = mark[v], mw = mark[w & WaNbT<NB>::IDM];
-        unsigned long long m = mask[e];
+        unsigned long long m = wa_mask_get(mask, e);
         float p = pher[e];
         const bool v_best = mv == ver;
         if (skip_best_src && v_best) continue;
@@ -1517,7 +1545,7 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
             p += s_dep[b] + bonus;  // :210-211
         }
         pher[e] = p;
-        mask[e] = 0;
+        wa_mask_clear(mask, e);
     }
 }
 
@@ -1710,7 +1738,7 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
     const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
     const int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
     float *pher = D.pher + (int64_t)slot * D.pher_stride;
-    unsigned long long *mask = D.mask + (int64_t)slot * D.pher_stride;
+    const WaMaskRef mask = wa_mask_of(D, slot);
     const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     float *T = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
     const int k = lane < 26 ? lane : 25;
@@ -1729,7 +1757,7 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
             int32_t nb = v + dk;
             nb = nb < 0 ? 0 : nb > last_id ? last_id : nb;    // (an out-of-bounds edge is inadmissible by its sign bit whatever is found here)
             const uint32_t mk = mark[nb];
-            unsigned long long m = apply_here ? mask[e] : 0ULL;
+            unsigned long long m = apply_here ? wa_mask_get(mask, e) : 0ULL;
             if (m) {  // somebody walked (v, lane): the ranked deposits in ascending rank order (:210-211); v is on the best path (:209)
                 const float bonus = (float)(mk == ver) * lambda * Q / bestL;
                 while (m) {
@@ -1738,7 +1766,7 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
                     p += s_dep[bq] + bonus;
                 }
                 pher[e] = p;
-                mask[e] = 0;
+                wa_mask_clear(mask, e);
             }
             if ((__float_as_uint(p) >> 31) == 0)              // in bounds and free (:148)
                 adm = !(mk == ver && pos[nb] <= i);           // not on the prefix best[0..i] (:145-146)
