@@ -938,10 +938,9 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 // the table depends on -- and blocks [TB, TB + 8*64) are the ordinary apply pass, which skips exactly
 // those edges.  The two roles touch disjoint edges, so no ordering between them is needed.
 #define WA_TABLE_BLOCKS 32
-#ifndef WA_APPLY_SPLIT_LOG2
-#define WA_APPLY_SPLIT_LOG2 2   // apply blocks per depositing rank in k_apply_table = 1 << this (8 blocks per rank: no faster)
-#endif
-__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
+// split_log2: apply blocks per depositing rank = 1 << this (the host passes 2 for one or a few searches -- 8 blocks per rank are no
+// faster --, 1 for launches that carry 32 searches or more)
+__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_t split_log2)
 {
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y;
@@ -959,8 +958,8 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R)
         wa_table_rows(D, R, slot, row0, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep, w0, w1);
         return;
     }
-    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..(ranks << WA_APPLY_SPLIT_LOG2)-1: (bx, rank bit)
-    wa_apply_body<6>(D, slot, 0, ab >> WA_APPLY_SPLIT_LOG2, ab & ((1 << WA_APPLY_SPLIT_LOG2) - 1), 1 << WA_APPLY_SPLIT_LOG2, true, s_dep);
+    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..(ranks << split_log2)-1: (bx, rank bit)
+    wa_apply_body<6>(D, slot, 0, ab >> split_log2, ab & ((1 << split_log2) - 1), 1 << split_log2, true, s_dep);
 }
 
 // DEV: grid = (max_colony, n_problems), block = one wavefront
@@ -1296,12 +1295,11 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // PUBLISHES what k_rank publishes (global best, perm/depA for the apply pass, trace, the next
 // generation's parameters -- into slot [(gen+1)&1], which nobody reads during this launch).
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
-#ifndef WA_MARK_SPLIT_LOG2
-#define WA_MARK_SPLIT_LOG2 2   // mark blocks per depositing rank in the fused launch = 1 << this (C3, 500 generations: 8 blocks 21.6 k gen/s, 4 22.1 k, 2 21.9 k)
-#endif
+// split_log2: mark blocks per depositing rank = 1 << this (C3, 500 generations: 8 blocks per rank 21.6 k gen/s, 4 22.1 k, 2 21.9 k;
+// C5 with 224 searches per launch: 4 blocks 0.636 s, 2 0.622 s, 1 0.623 s) -- the host passes 2 or 1
 template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB)
+                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -1428,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         }
     }
     // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
-    const int32_t bit = mb >> WA_MARK_SPLIT_LOG2, bx = mb & ((1 << WA_MARK_SPLIT_LOG2) - 1), o = bit + 1;
+    const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
     if (o > n_dep) return;
     const int32_t a = s_perm[o - 1];
     const int32_t len = antLen[a];
@@ -1436,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const WaMaskRef mask = wa_mask_of(D, slot);
     float *ph = dst_base + (int64_t)slot * D.pher_stride;
     const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
-    for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += (blockDim.x << WA_MARK_SPLIT_LOG2)) {
+    for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += (blockDim.x << split_log2)) {
         int32_t w = path[i];
         int32_t v = path[i - 1] & WaNbT<NB>::IDM;
         int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
