@@ -106,9 +106,12 @@ typedef struct {
 } wa_acs_params;
 void wa_acs_default_params(wa_acs_params *p);
 
-/* n_slots independent problems can be in flight (each owns a pheromone field: 24 B/voxel, a
- * heuristic field: 24 B/voxel, a deposit mask: 48 B/voxel).  max_colony bounds the ants per
- * generation, path_capacity the nodes per walk (<= number of voxels). */
+/* n_slots independent problems can be in flight.  Each owns a pheromone field (24 B/voxel, two of them with the dense
+ * sweep: it is out of place), best-path stamps (8 B/voxel), deposit rank masks (6 B/voxel when max_colony <= 35 --
+ * at most 8 ranks deposit, ACSRank_3D.hpp:200 -- 48 B/voxel otherwise) and its ants' paths (4 B * max_colony *
+ * path_capacity); the heuristic fields (24 B/voxel) are a pool shared by the slots: one per distinct END point in use,
+ * computed by wa_acs_begin when the pool does not hold it yet.  max_colony bounds the ants per generation,
+ * path_capacity the nodes per walk (<= number of voxels). */
 int wa_acs_create(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                   int64_t path_capacity, wa_acs **out);
 /* Same with an explicit neighbourhood: 6 = face neighbours (what wa_acs_create builds, the reference as
