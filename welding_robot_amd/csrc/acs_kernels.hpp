@@ -672,7 +672,7 @@ __device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const
     }
 }
 
-template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true>
+template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
@@ -757,7 +757,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #ifndef WA_STAMPS
     use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
 #endif
-    if (st.len < fast_limit && use_asm && prefix_words && (walk_flags & 2)) {
+    if (REJ && st.len < fast_limit && use_asm && prefix_words && (walk_flags & 2)) {
         // The ant replayed a prefix of the best path and left it.  Measured: such an ant is back on the path after a
         // median of 3-4 steps and 82-92 % of its remaining nodes lie on it, so the general loop runs with a rejoin watch and every
         // time the ant is found on the path again it goes back onto the replay track for as long as the table applies to it.
@@ -965,7 +965,10 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 // DEV: grid = (max_colony, n_problems), block = one wavefront
 // WARM: the hand-scheduled loop touches the records two hops ahead of the ant (pays while a search has the GPU to itself, costs
 // when many searches saturate it: see walk_loop_gfx950.hpp)
-template <bool ALPHA1, bool SPARSE, bool WARM = true>
+// REJ: the kernel carries the rejoin watch + re-entry onto the replay track.  The host launches the instantiation without it for
+// the first generations of a search, in which the watch cannot be armed yet (it waits for a best path that has been stable for
+// WA_REENTRY_STABLE generations): the mere presence of that code costs the exploratory walk 1.5 % (187 vs 190 us per launch).
+template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     // the rejoin watch pays once the colony has settled on the best path (it costs a failed attempt every few steps while the
     // ants still explore): it is switched on when that path has not changed for a number of generations
     if (gen - c->tabu_gen < ((walk_flags >> 24) & 127)) walk_flags &= ~2;
-    wa_walk_one<1, ALPHA1, SPARSE, WARM>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
+    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot);
 }
 
