@@ -292,12 +292,17 @@
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
 
+// Where the loop sits relative to the 64-byte instruction lines moves a step by up to 2 % (its branch targets: four step heads, the
+// collision and rare-event stubs).  Measured at C3, walk launches of generations 0-10, loop top at 64 B + 4k bytes: k = 0 190.0 us,
+// 2 188.7, 4 187.1, 6 187.5, 8 190.4, 10 189.7, 12 186.7, 14 187.1 -- so the dense loops are pinned at k = 12 instead of left to
+// whatever the code in front of them happens to add up to.
+#define WA_ASM_LOOP_ALIGN ".p2align 6\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
 #define WA_ASM_REJ_INIT "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n"
 #define WA_ASM_REJ_EXITS WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
 // the two dense loops as statements (W = SELF | NONE: the touch loads, see above)
 #define WA_ASM_RUN_DENSE(W)                                                                                       \
     asm volatile(                                                                                                 \
-        WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT                                                                        \
+        WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT WA_ASM_LOOP_ALIGN                                                      \
         "Lwa_top%=:\n"                                                                                            \
         WA_ASM_STEP("v71", "v72", "v73", "v74", "a", W)                                                           \
         WA_ASM_STEP("v73", "v74", "v71", "v72", "b", W)                                                           \
@@ -316,7 +321,7 @@
         WA_ASM_PROLOGUE                                                                                           \
         "ds_read_b32 v94, %[lc] offset:3584\n"        /* lanes 3, 4: best-path version, hold-off */               \
         "s_waitcnt lgkmcnt(0)\n"                                                                                  \
-        WA_ASM_REJ_INIT                                                                                           \
+        WA_ASM_REJ_INIT WA_ASM_LOOP_ALIGN                                                                         \
         "Lwa_top%=:\n"                                                                                            \
         WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a", W)                                                       \
         WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b", W)                                                       \
