@@ -48,6 +48,9 @@ const char *wa_version(void);
 /* visible HIP devices (0 when there is none or no runtime): the drop-in ACS_Rank shards its pair searches over all of
  * them, one wa_ctx per device (ACSRank_3D.hpp:472-499 is a loop over independent searches) */
 int wa_device_count(void);
+/* free / total memory of the context's device in bytes (either pointer may be NULL): what the slot count of a solver for many
+ * pair searches is sized by, and what a caller can poll after another process has just released the GPU */
+int wa_ctx_memory_info(wa_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling
  * thread's current HIP device, and restores the caller's current device before returning. */
 int wa_ctx_create(int device_ordinal, wa_ctx **out);

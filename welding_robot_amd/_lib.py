@@ -32,6 +32,7 @@ _V, _I, _I64, _F, _P = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SYMBOLS = {
     "wa_version": (C.c_char_p, []),
     "wa_device_count": (C.c_int, []),
+    "wa_ctx_memory_info": (C.c_int, [_V, _P, _P]),
     "wa_ctx_create": (C.c_int, [C.c_int, C.POINTER(_V)]),
     "wa_ctx_destroy": (None, [_V]),
     "wa_last_error": (C.c_char_p, [_V]),

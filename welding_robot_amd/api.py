@@ -47,6 +47,12 @@ class Context:
     def stream(self):
         return self.lib.wa_ctx_stream(self.h)
 
+    def memory_info(self):
+        """(free, total) bytes of device memory"""
+        f, t = C.c_int64(), C.c_int64()
+        self.check(self.lib.wa_ctx_memory_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def sync(self):
         self.check(self.lib.wa_ctx_sync(self.h))
 

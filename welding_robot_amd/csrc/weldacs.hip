@@ -159,6 +159,16 @@ int wa_device_count(void)
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+int wa_ctx_memory_info(wa_ctx *c, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!c) return WA_ERR_ARG;
+    WaDevGuard dev_guard_(c);
+    size_t f = 0, t = 0;
+    HIPC(c, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return WA_OK;
+}
 void wa_ctx_destroy(wa_ctx *c)
 {
     if (!c) return;
