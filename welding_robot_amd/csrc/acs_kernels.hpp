@@ -49,8 +49,8 @@ struct WaAcsDev {
     // edges are worth ctl.clean (or 0 where the stored value is 0).  A deposited ("dirty") voxel carries
     // stamp = 1 + the evaporation count its stored record is current for; whoever needs the record later applies the
     // missing multiplications by rho one by one (same fp32 roundings as the sweep).  Records are brought current when
-    // they receive a deposit, and every WA_LAZY_PERIOD generations by a background pass over 1/WA_LAZY_PERIOD of the
-    // dirty list, so at most WA_LAZY_PERIOD multiplications are ever pending.  dcount[slot][2] = {list entries the
+    // they receive a deposit, and every `period` generations (16 or 64, see k_evap_rank_mark) by a background pass over 1/period of the
+    // dirty list, so about that many multiplications at most are ever pending.  dcount[slot][2] = {list entries the
     // background pass may touch, append cursor}.  All null in the (default) dense mode.
     uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
@@ -182,9 +182,6 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
 }
 
 
-#ifndef WA_LAZY_PERIOD
-#define WA_LAZY_PERIOD 16
-#endif
 // stored value -> value after `lag` more evaporations (:270, one rounding per multiplication like the sweep)
 __device__ __forceinline__ float wa_catch_up(float v, uint32_t lag, float rho)
 {
@@ -1302,7 +1299,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // C5 with 224 searches per launch: 4 blocks 0.636 s, 2 0.622 s, 1 0.623 s) -- the host passes 2 or 1
 template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2)
+                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -1312,8 +1309,11 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
                           (int32_t)blockIdx.x - MB, E);
         } else {
-            // lazy evaporation, background pass: every WA_LAZY_PERIOD-th entry of the dirty list (phase = generation)
-            // is brought current in place, so no record ever has more than WA_LAZY_PERIOD multiplications pending.
+            // lazy evaporation, background pass: every lazy_period-th entry of the dirty list (phase = generation) is brought
+            // current in place, so no record has more than ~lazy_period multiplications pending (whoever reads a record applies
+            // the pending ones exactly, one rounding each: the period only trades this pass against those catch-ups; the host
+            // passes 16 for a few searches per launch and 64 for 64 and more -- C5, 224 searches: 16 0.618 s, 32 0.583, 64 0.570,
+            // 256 0.563; the 32-search pair planning of bench.py: 325 k / 320 k / 303 k pair-generations/s with 16 / 32 / 64)
             // A record is claimed by exchanging its stamp (the mark blocks of this launch claim the same way when a
             // voxel receives a deposit), so exactly one thread applies the pending multiplications.
             float *ph = dst_base + (int64_t)slot * D.pher_stride;
@@ -1323,9 +1323,9 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)gen;
             const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
             const float rho = R.rho;
-            const int64_t first = (int64_t)(evap_now % WA_LAZY_PERIOD);
-            for (int64_t q = first + (int64_t)WA_LAZY_PERIOD * ((int64_t)((int32_t)blockIdx.x - MB) * blockDim.x + tid); q < n0;
-                 q += (int64_t)WA_LAZY_PERIOD * E * blockDim.x) {
+            const int64_t first = (int64_t)(evap_now % (uint32_t)lazy_period);
+            for (int64_t q = first + (int64_t)lazy_period * ((int64_t)((int32_t)blockIdx.x - MB) * blockDim.x + tid); q < n0;
+                 q += (int64_t)lazy_period * E * blockDim.x) {
                 const int32_t v = list[q];
                 const uint32_t old = atomicExch(&stamp[v], target);
                 if (old == target) continue;

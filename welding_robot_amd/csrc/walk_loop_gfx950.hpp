@@ -75,6 +75,18 @@
     "v_and_b32 v78, 0x7fffffff, " CP "\n"                                                                         \
     "s_cmp_eq_u32 s37, 0\n"                                                                                       \
     "s_cbranch_scc1 Lwa_dirty2_" X "%=\n"                                                                         \
+    "Lwa_catch4_" X "%=:\n"                                       /* four pending evaporations at a time (one rounding each, in order) ... */ \
+    "s_cmp_lt_u32 s37, 4\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_catch1_" X "%=\n"                                                                         \
+    "v_mul_f32 v78, s35, v78\n"                                                                                   \
+    "v_mul_f32 v78, s35, v78\n"                                                                                   \
+    "v_mul_f32 v78, s35, v78\n"                                                                                   \
+    "v_mul_f32 v78, s35, v78\n"                                                                                   \
+    "s_sub_u32 s37, s37, 4\n"                                                                                     \
+    "s_branch Lwa_catch4_" X "%=\n"                                                                               \
+    "Lwa_catch1_" X "%=:\n"                                       /* ... then the last one to three */             \
+    "s_cmp_eq_u32 s37, 0\n"                                                                                       \
+    "s_cbranch_scc1 Lwa_dirty2_" X "%=\n"                                                                         \
     "Lwa_catch_" X "%=:\n"                                                                                        \
     "v_mul_f32 v78, s35, v78\n"                                                                                   \
     "s_sub_u32 s37, s37, 1\n"                                                                                     \
