@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=GRID_N)
     ap.add_argument("--ants", type=int, default=ANTS)
     ap.add_argument("--cpu-gens", type=int, default=20, help="generations of the CPU baseline sample")
+    ap.add_argument("--cost-check-gens", type=int, default=None, help="generations the CPU port replays for cost_check (default: all K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary C5-shaped pair-planning measurement")
@@ -57,9 +58,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl):
+def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl, gpu_path, K):
     """Reported baseline (never the target).  Same grid, same parameters, first `cpu_gens`
-    generations (the longest walks of the run); 1 thread like the reference."""
+    generations (the longest walks of the run); 1 thread like the reference.
+    cost_check: the DEV-mode port draws the same numbers as the GPU, so ALL K generations of the timed search are
+    replayed on the CPU (66 s for 500) and the per-generation best cost, the iteration best, the step counts and the
+    final best path must be equal bit for bit."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O  # cpu_baseline leg only
@@ -67,15 +71,26 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl):
     og = O.Grid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), free, 1.0, 0)
     sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, n - 1, np.float32))
     out = {}
-    # cost check: the DEV-mode port draws the same numbers as the GPU, so best cost must be equal
     a = O.Acs(og)
     t0 = time.time()
     tr = a.solve(sid, eid, G, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
     t_port = time.time() - t0
     port_rate = G / t_port
-    cost_equal = bool(np.array_equal(tr["bestL"].view(np.uint32), gpu_trace["bestL"][:G].view(np.uint32)))
-    out["cost_check"] = {"generations": G, "cpu_best_cost": float(tr["bestL"][-1]), "gpu_best_cost": float(gpu_trace["bestL"][G - 1]),
-                         "bit_equal_trace": cost_equal}
+    KC = K if args.cost_check_gens is None else min(K, args.cost_check_gens)
+    if KC > G:
+        a = O.Acs(og)
+        tr = a.solve(sid, eid, KC, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
+    else:
+        KC = G
+    bit = lambda x: np.ascontiguousarray(x, np.float32).view(np.uint32)
+    cost_equal = bool(np.array_equal(bit(tr["bestL"]), bit(gpu_trace["bestL"][:KC])) and
+                      np.array_equal(bit(tr["iterbestL"]), bit(gpu_trace["iterbestL"][:KC])) and
+                      np.array_equal(tr["steps"], gpu_trace["steps"][:KC]))
+    path_equal = bool(np.array_equal(a.best_path()[0], gpu_path)) if KC == K else None
+    out["cost_check"] = {"generations": KC, "of_timed_generations": K, "cpu_best_cost": float(tr["bestL"][-1]),
+                         "gpu_best_cost": float(gpu_trace["bestL"][KC - 1]),
+                         "bit_equal_trace": cost_equal, "best_path_equal": path_equal,
+                         "checked": "best cost, iteration best and total steps of every generation; node ids of the final best path"}
     sample = "generations 0..%d of the same %d^3 / %d-ant search (the run's longest walks); GPU took %.2f ms for the same window" % (
         G - 1, n, args.ants, gpu_first_ms)
     if O.have_ref():
@@ -231,9 +246,19 @@ def main():
     ctx.sync()
     setup_ms = (time.perf_counter() - t_setup) * 1e3
     solver.profile(True, args.profile_every)
-    ext = torch.cuda.ExternalStream(ctx.stream, device=dev) if dist_on else None
+    # global-best exchange (C4): libweldacs.so's own RCCL communicator (wa_comm_*, csrc/host_comm.inc -- what a C++ host uses);
+    # torch.distributed only ships the 128-byte id and provides the contract's barrier.  WA_BENCH_TORCH_ALLREDUCE=1 selects the
+    # round-2 path (torch.distributed all_reduce of the exported trace) instead.
     chunk = min(CHUNK, K)
-    gbuf = [torch.empty(chunk, dtype=torch.float32, device=dev) for _ in range((K + chunk - 1) // chunk)] if dist_on else []
+    use_torch_ar = dist_on and os.environ.get("WA_BENCH_TORCH_ALLREDUCE") == "1"
+    comm = None
+    if dist_on and not use_torch_ar:
+        uid = torch.from_numpy(api.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+        dist.broadcast(uid, src=0)
+        comm = api.Comm(ctx, rank, world, uid.cpu().numpy())
+        comm.barrier()
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev) if use_torch_ar else None
+    gbuf = [torch.empty(chunk, dtype=torch.float32, device=dev) for _ in range((K + chunk - 1) // chunk)] if use_torch_ar else []
     works = []
 
     def barrier():
@@ -248,13 +273,16 @@ def main():
     while done < K:
         c = min(chunk, K - done)
         solver.run(c)
-        if dist_on:  # global-best cost of generations done..done+c-1, MIN over ranks, async on RCCL
+        if comm is not None:   # MIN over ranks of best_L[done .. done+c), asynchronous on the communicator's stream
+            comm.allreduce_best(solver, done, c)
+        elif use_torch_ar:
             gb = gbuf[done // chunk]
             solver.export_trace(gb.data_ptr(), done, c)
             with torch.cuda.stream(ext):
                 works.append(wd.allreduce_min_(gb[:c], async_op=True))
         done += c
     solver.sync()
+    glob = comm.read_best(0, K) if comm is not None else None   # waits for the exchanges
     for w in works:
         if w is not None:
             w.wait()
@@ -267,10 +295,15 @@ def main():
     cost, path, _ = solver.result()
     trace = solver.trace()
     if dist_on:  # the reduced global-best history must be the element-wise MIN of the ranks' histories
-        glob = torch.cat([g[:min(chunk, K - i * chunk)] for i, g in enumerate(gbuf)]).cpu().numpy()
+        if glob is None:
+            glob = torch.cat([g[:min(chunk, K - i * chunk)] for i, g in enumerate(gbuf)]).cpu().numpy()
         assert glob.shape[0] == K and np.all(glob <= trace["bestL"] + 0.0), "global best exceeds a local best"
         if world == 1:
             assert np.array_equal(glob.view(np.uint32), trace["bestL"].view(np.uint32))
+        else:   # ... and somebody's local best: the MIN over ranks of the local histories, computed the slow way
+            allh = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(world)]
+            dist.all_gather(allh, torch.from_numpy(np.ascontiguousarray(trace["bestL"], np.float32)).to(dev))
+            assert np.array_equal(torch.stack(allh).min(0).values.cpu().numpy().view(np.uint32), glob.view(np.uint32)), "RCCL MIN != MIN of the gathered histories"
     best_all = wd.max_over_ranks(-float(cost), dev) * -1.0  # min over ranks
     if rank == 0:
         # ---- fused launch (sweep + rank + mark share it): >= 32 per-dispatch samples whatever --steps is
@@ -308,7 +341,9 @@ def main():
                                    "%d ants fixed, %d generations, alpha 1 beta 0.6 rho 0.8, DEV rng seed 12345+rank; "
                                    "one independent problem per GPU (C4)" % (n, args.ants, K),
                        "grid": [n, n, n], "ants": args.ants, "generations": K, "problems_per_gpu": 1,
-                       "global_best_allreduce": "RCCL MIN over ranks per generation, chunks of %d, async" % chunk if dist_on else "n/a (1 GPU)"},
+                       "global_best_allreduce": ("RCCL MIN over ranks per generation, chunks of %d, async, %s" % (
+                           chunk, "torch.distributed" if use_torch_ar else "libweldacs wa_acs_allreduce_best (ncclAllReduce ncclMin on the communicator's stream)"))
+                       if dist_on else "n/a (1 GPU)"},
             "roofline": {"bound": "hbm", "kernel": "k_evaporate (the evaporation sweep, launched alone %d times after the timed region; "
                                                    "per-dispatch HIP events on the library's stream)" % r128["launches"],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -338,12 +373,14 @@ def main():
             solver.run(G)
             solver.sync()
             gpu_first_ms = (time.perf_counter() - t1) * 1e3
-            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl))
+            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl, path, K))
         if world == 1:
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -193,6 +193,31 @@ int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
 /* evaporation sweep alone (ACSRank_3D.hpp:268-272) over `slot` -- for roofline measurements */
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats);
 
+/* ---- multi-GPU: problems shard one set per GPU (main.cpp:268-283 is a loop over independent searches, and so is a
+ *      multi-start batch); the only exchange is the global-best path cost per generation -- what each rank's
+ *      ACSRank_3D.hpp:263-264 would publish -- as an RCCL all-reduce (ncclMin) over xGMI.  One wa_comm per wa_ctx
+ *      (= per device, per process or host thread); libweldacs.so links librccl itself, no torch / MPI needed. ---- */
+#define WA_COMM_ID_BYTES 128
+typedef struct wa_comm wa_comm;
+/* rank 0 creates the id (ncclGetUniqueId) and ships the bytes to the other ranks by any means it has
+ * (a file, a socket, MPI_Bcast, a torch.distributed store ...) */
+int wa_comm_unique_id(uint8_t id_out[WA_COMM_ID_BYTES]);
+/* collective over all `world` ranks (ncclCommInitRank); the communicator runs its exchanges on its own stream */
+int wa_comm_create(wa_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[WA_COMM_ID_BYTES], wa_comm **out);
+void wa_comm_destroy(wa_comm *c);
+int wa_comm_info(const wa_comm *c, int32_t *rank, int32_t *world);
+/* global_best[g] = MIN over all ranks and all active slots of best_L[g] for g in [gen0, gen0 + count): asynchronous --
+ * waits (event) for the generations enqueued so far, runs on the communicator's stream beside the generations enqueued
+ * afterwards.  Every rank must call it with the same (gen0, count) sequence.  The global best is published, never fed
+ * back into a problem's own colony / Q, so per-problem results equal the single-GPU run. */
+int wa_acs_allreduce_best(wa_acs *s, wa_comm *c, int32_t gen0, int32_t count);
+/* wait for the exchanges enqueued so far, then copy global_best[gen0 .. gen0 + count) to the host */
+int wa_comm_read_best(wa_comm *c, int32_t gen0, int32_t count, float *out);
+/* bookkeeping helpers for a C++ launcher (timing max over ranks, totals): blocking all-reduce of host doubles */
+enum { WA_COMM_MIN = 0, WA_COMM_MAX = 1, WA_COMM_SUM = 2 };
+int wa_comm_allreduce_f64(wa_comm *c, double *inout, int32_t count, int32_t op);
+int wa_comm_barrier(wa_comm *c);
+
 /* ---- weld-seam ordering: replaces ACS_GTSP::readFromGraphFile's init + computeSolution
  *      (ACS_GTSP.hpp:187-218, :224-253, :255-284) ----------------------------------------- */
 typedef struct {

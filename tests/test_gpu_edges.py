@@ -170,6 +170,15 @@ def test_slot_that_sat_out_an_odd_number_of_generations_is_reused_without_reset(
     # ... and an idle slot can still be read back while the others moved on (an odd number of generations again)
     s.solve(p1, [0], [n - 1], streams=[5])
     assert np.array_equal(bits(s.pheromone(1)), bits(a1.pheromone()))
+    # ... and the stand-alone sweep (wa_acs_evaporate flips every slot) must carry the idle slot's LIVE field across, not the
+    # stale copy in the buffer it was last swept out of: slot 1 unchanged, slot 0 multiplied by rho once per repeat
+    f0 = s.pheromone(0)
+    s.evaporate(0, 0.5, 1)
+    assert np.array_equal(bits(s.pheromone(1)), bits(a1.pheromone()))
+    assert np.array_equal(bits(s.pheromone(0)), bits(f0 * np.float32(0.5)))
+    s.evaporate(1, 0.25, 3)
+    assert np.array_equal(bits(s.pheromone(1)), bits(((a1.pheromone() * np.float32(0.25)) * np.float32(0.25)) * np.float32(0.25)))
+    assert np.array_equal(bits(s.pheromone(0)), bits(f0 * np.float32(0.5)))
 
 
 def test_every_ant_of_a_generation_matches_the_oracle(ctx):

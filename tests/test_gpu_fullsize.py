@@ -61,14 +61,48 @@ def test_c3_dev_150_generations_trace_path_and_whole_field_equal_the_oracle(ctx)
     s.close()
 
 
-def test_c3_ref_40_generations_equal_the_reference(ctx):
-    """REF mode (libc stream, std::sort ties) against the reference's own 40 generations on the C3 grid: trace, path,
+def test_c3_dev_500_generations_at_its_stated_length_equal_the_oracle(ctx):
+    """BASELINE config 3 at its stated 500 iterations (ACSRank_3D.hpp:237-299): the fused sweep + rank + mark launch and
+    the 50-rank deposits carry the fp32 field through the denormal range (off-path edges: 1 * 0.8^t goes subnormal at
+    t ~ 392, :268-272) and onto the 2-ulp fixed point (t ~ 460).  Every generation's trace, the best path,
+    every ant's (L, length) and all 12.6 M pheromone values against the oracle, bit for bit."""
+    og = O.synth_grid(128, seed=2024, occ_prob=0.10)
+    s = api.AcsSolver(ctx, dgrid(ctx, og), n_slots=1, max_colony=256)
+    p = api.default_params(max_iteration=500, predict=731.43, fixed_colony=256, rng_mode=api.RNG_DEV, seed=12345)
+    s.solve(p, 16513, 2097151)
+    a = O.Acs(og)
+    tr = a.solve(16513, 2097151, 500, 731.43, fixed_colony=256, mode=O.DEV, seed=12345, stream=0)
+    t = s.trace()
+    assert len(t["bestL"]) == 500
+    for k in ("bestL", "iterbestL"):
+        assert np.array_equal(bits(t[k]), bits(tr[k])), k
+    for k in ("colony", "finite", "steps"):
+        assert np.array_equal(t[k], tr[k]), k
+    cost, path, ch = s.result()
+    ids, och = a.best_path()
+    assert bits(cost) == bits(a.best_L) and float(cost) == 378.0
+    assert np.array_equal(path, ids) and np.array_equal(ch.astype(np.int32), och)
+    L, lens = s.ants()
+    olens, oL = a.last_ants()
+    assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL))
+    f, of = s.pheromone(), a.pheromone()
+    assert np.array_equal(bits(f), bits(of))
+    # the regime this test is about really was reached: off-path in-bounds edges sit on the denormal fixed point
+    tiny = f[(f > 0) & (f < np.float32(1.1754944e-38))]
+    assert tiny.size > 6 * 128 ** 3 // 2 and bits(tiny.min()) == 2
+    s.close()
+
+
+@pytest.mark.parametrize("gens", [40, 500])
+def test_c3_ref_generations_equal_the_reference(ctx, gens):
+    """REF mode (libc stream, std::sort ties) against the reference's own 40 generations on the C3 grid and against its
+    full 500 (BASELINE config 3 as stated; denormal range and 2-ulp fixed point of the field included): trace, path,
     field hash and the position of the libc stream."""
-    g = waf.load(os.path.join(G, "acs_synth128_fixed256_40.waf"))
+    g = waf.load(os.path.join(G, "acs_synth128_fixed256_%d.waf" % gens))
     og = O.synth_grid(128, seed=2024, occ_prob=0.10)
     s = api.AcsSolver(ctx, dgrid(ctx, og), n_slots=1, max_colony=256)
     s.srand(12345)
-    p = api.default_params(max_iteration=40, predict=float(np.float32("731.43")), fixed_colony=256, rng_mode=api.RNG_REF)
+    p = api.default_params(max_iteration=gens, predict=float(np.float32("731.43")), fixed_colony=256, rng_mode=api.RNG_REF)
     s.solve(p, 16513, 2097151)
     cost, path, ch = s.result()
     assert bits(cost) == bits(g["best_L"]) and np.array_equal(path, g["best_path"]) and np.array_equal(ch.astype(np.int32), g["best_choice"])

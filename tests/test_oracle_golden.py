@@ -204,7 +204,8 @@ def test_acs_nan_seam_all_ants_die():
     assert np.isinf(acs.best_L) and len(acs.best_path()[0]) == 0
 
 
-@pytest.mark.parametrize("tag", ["acs_synth128_adaptive10", "acs_synth128_fixed256_4", "acs_synth128_fixed256_40"])
+@pytest.mark.parametrize("tag", ["acs_synth128_adaptive10", "acs_synth128_fixed256_4", "acs_synth128_fixed256_40",
+                                 "acs_synth128_fixed256_500"])   # the last: BASELINE config 3 at its stated length, ~1 min on one core
 def test_acs_synth128_golden(tag):
     grid = O.synth_grid(128, seed=2024, occ_prob=0.10)
     g = _g(tag + ".waf")

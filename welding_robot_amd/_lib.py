@@ -74,6 +74,14 @@ SYMBOLS = {
     "wa_acs_profile_read": (C.c_int, [_V, _P, _P]),
     "wa_acs_debug_counters": (C.c_int, [_V, _P, _I]),
     "wa_acs_evaporate": (C.c_int, [_V, _I, _F, _I]),
+    "wa_comm_unique_id": (C.c_int, [_P]),
+    "wa_comm_create": (C.c_int, [_V, _I, _I, _P, C.POINTER(_V)]),
+    "wa_comm_destroy": (None, [_V]),
+    "wa_comm_info": (C.c_int, [_V, _P, _P]),
+    "wa_acs_allreduce_best": (C.c_int, [_V, _V, _I, _I]),
+    "wa_comm_read_best": (C.c_int, [_V, _I, _I, _P]),
+    "wa_comm_allreduce_f64": (C.c_int, [_V, _P, _I, _I]),
+    "wa_comm_barrier": (C.c_int, [_V]),
     "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),
     "wa_traj_stitch": (C.c_int, [_V, _P, _P, _I, _P, C.POINTER(_V)]),
     "wa_traj_from_points": (C.c_int, [_V, _P, _I64, C.POINTER(_V)]),
@@ -91,22 +99,23 @@ SYMBOLS = {
     "wa_bspline_sample": (C.c_int, [_V, _F, _F, _I64, _I, _P, _P, C.POINTER(_V)]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """path: an alternative build of the same library (the -DWA_TEST_KNOBS build of tests/test_gpu_reentry.py)"""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise ImportError("libweldacs.so is not built (%s). Run `python -m welding_robot_amd.build` "
-                              "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+                              "or __graft_entry__.build(); there is no CPU fallback." % path)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 class WeldacsError(RuntimeError):

@@ -14,8 +14,8 @@ def _ptr(a):
 
 
 class Context:
-    def __init__(self, device=0):
-        self.lib = L.load()
+    def __init__(self, device=0, lib_path=None):
+        self.lib = L.load(lib_path)
         h = C.c_void_p()
         rc = self.lib.wa_ctx_create(device, C.byref(h))
         if rc:
@@ -29,7 +29,7 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            for ch in sorted(list(self._children), key=lambda o: 0 if isinstance(o, AcsSolver) else 1):
+            for ch in sorted(list(self._children), key=lambda o: 0 if isinstance(o, (AcsSolver, Comm)) else 1):
                 ch.close()
             self.lib.wa_ctx_destroy(self.h)
             self.h = None
@@ -279,6 +279,53 @@ class AcsSolver:
 
     def evaporate(self, slot=0, rho=0.8, repeats=1):
         self.ctx.check(self.ctx.lib.wa_acs_evaporate(self.h, slot, C.c_float(rho), repeats))
+
+
+class Comm:
+    """wa_comm: RCCL communicator behind the C ABI (csrc/host_comm.inc) -- the global-best exchange of the multi-GPU path.
+    Rank 0 makes the id (Comm.unique_id()), the caller ships the 128 bytes to the other ranks."""
+
+    @staticmethod
+    def unique_id(lib_path=None):
+        buf = np.zeros(128, np.uint8)
+        rc = L.load(lib_path).wa_comm_unique_id(_ptr(buf))
+        if rc:
+            raise WeldacsError(rc, "wa_comm_unique_id failed")
+        return buf
+
+    def __init__(self, ctx, rank, world, uid):
+        self.ctx = ctx
+        uid = np.ascontiguousarray(uid, np.uint8)
+        assert uid.size == 128
+        h = C.c_void_p()
+        ctx.check(ctx.lib.wa_comm_create(ctx.h, rank, world, _ptr(uid), C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.wa_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def allreduce_best(self, solver, gen0, count):
+        """asynchronous: MIN over ranks (and active slots) of best_L[gen0 .. gen0+count)"""
+        self.ctx.check(self.ctx.lib.wa_acs_allreduce_best(solver.h, self.h, gen0, count))
+
+    def read_best(self, gen0, count):
+        out = np.empty(count, np.float32)
+        self.ctx.check(self.ctx.lib.wa_comm_read_best(self.h, gen0, count, _ptr(out)))
+        return out
+
+    def allreduce(self, values, op="max"):
+        v = np.ascontiguousarray(np.atleast_1d(values), np.float64).copy()
+        self.ctx.check(self.ctx.lib.wa_comm_allreduce_f64(self.h, _ptr(v), v.size, {"min": 0, "max": 1, "sum": 2}[op]))
+        return v
+
+    def barrier(self):
+        self.ctx.check(self.ctx.lib.wa_comm_barrier(self.h))
 
 
 class Trajectory:

@@ -15,9 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libweldacs.so")
+# the same library with the forced-hand-back knobs of tests/test_gpu_reentry.py compiled in (-DWA_TEST_KNOBS); never the product
+KNOBS_LIB_PATH = os.path.join(LIB_DIR, "libweldacs_knobs.so")
 SOURCES = ["weldacs.hip"]
 DEPS = ["wa_device.h", "acs_kernels.hpp", "walk_loop_gfx950.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp", "traj_kernels.hpp",
-        "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc"]
+        "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc", "host_comm.inc"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -32,10 +34,11 @@ def hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def needs_build(lib=None):
+    lib = lib or LIB_PATH
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib)
     files = [os.path.join(CSRC, f) for f in SOURCES + DEPS] + [HEADER, os.path.abspath(__file__)]
     return any(os.path.getmtime(f) > t for f in files)
 
@@ -46,15 +49,26 @@ def build(force=False, verbose=False, extra=(), out=None):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     out = out or LIB_PATH
-    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    # librccl: the global-best all-reduce of the multi-GPU path (csrc/host_comm.inc) -- linked by the library itself
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return out
 
 
+def build_knobs(force=False, verbose=False):
+    """lib/libweldacs_knobs.so: what tests/test_gpu_reentry.py loads (api.Context(lib_path=...))"""
+    if not force and not needs_build(KNOBS_LIB_PATH):
+        return KNOBS_LIB_PATH
+    return build(force=True, verbose=verbose, extra=["-DWA_TEST_KNOBS"], out=KNOBS_LIB_PATH)
+
+
 if __name__ == "__main__":
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    if "--knobs" in sys.argv:
+        print(build_knobs(force="--force" in sys.argv, verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None,
                 extra=defs + (["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])))

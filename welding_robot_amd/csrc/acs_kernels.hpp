@@ -762,17 +762,24 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         const int32_t *bpos = D.bestpos + (int64_t)slot * D.d.n;
         const uint8_t *btabu = D.besttabu + (int64_t)slot * D.path_cap;
         const float *RT = D.rtab + (int64_t)slot * D.path_cap * 8;
+        // forced hand-backs are test knobs (tests/test_gpu_reentry.py): compiled only into the -DWA_TEST_KNOBS build of the library
+#ifdef WA_TEST_KNOBS
+        const bool knob_never = walk_flags & 4, knob_anywhere = walk_flags & 8;
         int32_t hold = ((walk_flags >> 8) & 0xffff) ? ((walk_flags >> 8) & 0xffff) : 1, backoff = 1;
+#else
+        constexpr bool knob_never = false, knob_anywhere = false;
+        int32_t hold = 1, backoff = 1;
+#endif
         for (;;) {
             wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
-                                             D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, (walk_flags & 8) ? 0u : best_ver, hold);
+                                             D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
             if (st.done || st.reason != 4) break;
             int32_t gained = 0;
             const uint32_t mk = mark[st.cur];
             const int32_t ps = bpos[st.cur];                      // (fetched beside the stamp, meaningful only under it)
             const int32_t q = mk == best_ver ? ps : -1;
-            if (q >= 0 && q < rlen - 1 && !(walk_flags & 4)) {
+            if (q >= 0 && q < rlen - 1 && !knob_never) {
                 int32_t room = spill_at - st.len;                 // nodes the tabu hash / the path may still take
                 if ((int32_t)D.path_cap - st.len < room) room = (int32_t)D.path_cap - st.len;
                 int32_t stop = q;

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -26,6 +27,7 @@ struct wa_ctx {
     hipStream_t stream;    // every kernel of this context
     std::string err;
     hipDeviceProp_t prop;
+    bool lds_attr_set = false;   // dynamic-LDS limit of the walk kernels raised on this device (wa_acs_run)
 };
 struct wa_grid {
     wa_ctx *ctx;
@@ -60,7 +62,6 @@ struct wa_acs {
     int cur_buf;
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
-    bool lds_attr_set;
     int walk_warm;         // touch loads in the hand-scheduled loop: -1 by launch size (wa_acs_run), 0 / 1 forced (WA_WALK_WARM)
     int walk_flags;        // k_walk_dev's switches: hand-scheduled loop, re-entry onto the replay track (WA_REENTRY=0: off), see acs_create
     WaRun R;
@@ -68,7 +69,7 @@ struct wa_acs {
     bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
     std::vector<int> lazy_mode;         // per slot: init mode of the stored records (-1 unknown)
     std::vector<float> lazy_p0;
-    int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks;
+    int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks, lazy_blocks_env;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
     int32_t *d_hslot, *d_hlist, *d_hends;   // per search: the heuristic field it reads / the fields wa_acs_begin computes and their end points
@@ -134,7 +135,11 @@ static int env_int(const char *name, int def)
 
 extern "C" {
 
-const char *wa_version(void) { return "weldacs 0.1 (gfx950)"; }
+#ifdef WA_TEST_KNOBS
+const char *wa_version(void) { return "weldacs 0.3 (gfx950, test knobs)"; }
+#else
+const char *wa_version(void) { return "weldacs 0.3 (gfx950)"; }
+#endif
 
 int wa_ctx_create(int device_ordinal, wa_ctx **out)
 {
@@ -163,6 +168,7 @@ int wa_ctx_memory_info(wa_ctx *c, int64_t *free_bytes, int64_t *total_bytes)
 {
     if (!c) return WA_ERR_ARG;
     WaDevGuard dev_guard_(c);
+    if (!dev_guard_.ok) return WA_ERR_DEVICE;   // the context's device could not be made current
     size_t f = 0, t = 0;
     HIPC(c, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = (int64_t)f;
@@ -186,6 +192,7 @@ int wa_ctx_device_name(const wa_ctx *c, char *buf, size_t cap)
 int wa_ctx_sync(wa_ctx *c)
 {
     WaDevGuard dev_guard_(c);
+    if (!dev_guard_.ok) return WA_ERR_DEVICE;   // the context's device could not be made current
     if (!c) return WA_ERR_ARG;
     HIPC(c, hipStreamSynchronize(c->stream));
     return WA_OK;
@@ -196,5 +203,6 @@ void *wa_ctx_stream(wa_ctx *c) { return c ? (void *)c->stream : nullptr; }
 #include "host_acs.inc"
 #include "host_gtsp.inc"
 #include "host_traj.inc"
+#include "host_comm.inc"
 
 }  // extern "C"

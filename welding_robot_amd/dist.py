@@ -27,8 +27,10 @@ def per_rank_workload(rank, grid_seed=2024, rng_seed=12345):
 def allreduce_min_(t, async_op=False):
     """global best cost per generation: element-wise MIN over ranks, in place"""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return None
+    # a process group of ONE rank (torchrun --nproc-per-node 1 with WA_FORCE_DIST=1) still issues the collective:
+    # that is how a 1-GPU box runs the RCCL call itself
     return dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=async_op)
 
 
