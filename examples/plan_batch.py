@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config C5 in miniature or at full size: P weld points on an n^3 grid, all P(P-1)/2
 pair searches (ACS_Rank::searchBestPathOfPoints' loop, ACSRank_3D.hpp:472-499) batched across the
-slots of each GPU and sharded round-robin across ranks, then the weld-seam order by the ACS-TSP
+slots of each GPU and dealt longest-first across ranks, then the weld-seam order by the ACS-TSP
 kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip), then
 (single-rank runs) the tour's segments stitched and smoothed on the device (main.cpp:283-352).
 
@@ -30,11 +30,17 @@ from welding_robot_amd import dist as wd  # noqa: E402
 def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=1, fixed_colony=0, lazy=False):
     P = len(point_ids)
     pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
-    mine = wd.shard_problems(len(pairs), rank, world)
-    # searches with the same end point share one heuristic field inside a batch (wa_acs_begin): run them side by side.
-    # (Results do not depend on the order: every search draws from the stream of its global pair index.)
-    mine = sorted(mine, key=lambda k: (pairs[k][1], pairs[k][0]))
+    # dealing and order: longest-processing-time-first over end-point groups (welding_robot_amd/dist.py: deal_pairs -- the rule
+    # of the drop-in C++ pair loop).  Results do not depend on either: every search draws from the stream of its global pair index.
+    nx, nxy = grid.nx, grid.nx * grid.ny
+    vox = [(int(v) // nxy, (int(v) // nx) % grid.ny, int(v) % nx) for v in point_ids]
+    weights = [1 + sum(abs(a - b) for a, b in zip(vox[i], vox[j])) for i, j in pairs]
+    shards, _ = wd.deal_pairs(pairs, weights, world)
+    mine = shards[rank]
     colony = fixed_colony or max(1, int(0.35 * predict / float(grid.precision)))
+    if not slots:   # sized by rule: free memory, footprint limit, whole batches
+        slots, _ = api.pair_slots_by_rule(ctx, grid, colony, max(1, len(mine)), len({pairs[k][1] for k in mine}), generations, lazy=lazy)
+    plan.last_slots = slots
     t_create = time.perf_counter()
     solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony, lazy=lazy)
     ctx.sync()
@@ -72,7 +78,7 @@ def main():
     ap.add_argument("--grid", type=int, default=96)
     ap.add_argument("--points", type=int, default=16)
     ap.add_argument("--generations", type=int, default=150)
-    ap.add_argument("--slots", type=int, default=16)
+    ap.add_argument("--slots", type=int, default=0, help="concurrent pair searches per GPU; 0 = sized by rule (memory, whole batches)")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--lazy", action="store_true",
                     help="wa_acs_create_lazy: never-deposited voxels are not swept (same results, O(deposited voxels) per generation)")
@@ -100,7 +106,7 @@ def main():
     t_pairs = time.perf_counter() - t0
     finite = np.isfinite(cost).all()
     t_pairs -= plan.last_create_s
-    out = dict(grid=n, points=args.points, lazy_evaporation=bool(args.lazy), t_solver_create_s=plan.last_create_s, pairs=args.points * (args.points - 1) // 2, world=world,
+    out = dict(grid=n, points=args.points, slots=plan.last_slots, lazy_evaporation=bool(args.lazy), t_solver_create_s=plan.last_create_s, pairs=args.points * (args.points - 1) // 2, world=world,
                pairs_this_rank=n_mine, t_pairs_s=t_pairs, all_reached=bool(finite))
     if rank == 0 and finite:
         t1 = time.perf_counter()

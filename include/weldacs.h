@@ -138,6 +138,12 @@ int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t 
 int wa_acs_create_lazy(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                        int64_t path_capacity, wa_acs **out);
 void wa_acs_destroy(wa_acs *s);
+/* device bytes a solver of this shape takes: per slot, per heuristic field (the pool holds one per distinct END point of a
+ * batch, at least min(n_slots, 4)) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.
+ * Nothing is allocated.  The drop-in ACS_Rank sizes the concurrent pair searches of a device from this and
+ * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another). */
+int wa_acs_memory_estimate(const wa_grid *grid, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood, int32_t lazy,
+                           int64_t *bytes_per_slot, int64_t *bytes_per_heuristic_field, int64_t *bytes_fixed);
 /* initFromGridMap :343-408: in-bounds edges pheromone_0, out-of-bounds edges 0. slot<0: all */
 int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float pheromone_0);
 /* reset() :307-315: every edge pheromone_0 */

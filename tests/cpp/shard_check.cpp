@@ -1,6 +1,7 @@
 // shard_check.cpp -- test helper: ACS_Rank::searchBestPathOfPoints (ACSRank_3D.hpp:427-504) sharded over a device list.
-//   shard_check <stl> <precision> <wall> <points.in> <predict> <seed> <devices: "all" | "0" | "0,0" ...> <dump.txt>
-// dump: one line per ordered pair i<j: "pair i j COSTBITS len id id id ..." + the cost matrix
+//   shard_check <stl> <precision> <wall> <points.in> <predict> <seed> <devices: "all" | "0" | "0,0" ...> <dump.txt> [slots: 0 = sized by rule]
+// dump: one line per ordered pair i<j: "pair i j COSTBITS len id id id ..." + the cost matrix; <dump>.shards: one line per shard
+// "shard d device pairs slots batches weight" (ACS_Rank::lastShards())
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +21,7 @@ int main(int argc, char **argv)
     sp.setRngMode(WA_RNG_DEV);
     sp.setSeed((uint64_t)atoll(argv[6]));
     sp.setMaxIteration(60);
-    sp.setConcurrentPairs(3);
+    sp.setConcurrentPairs(argc > 9 ? atoi(argv[9]) : 3);
     if (strcmp(argv[7], "all")) {
         std::vector<int> d;
         for (char *t = strtok(argv[7], ","); t; t = strtok(NULL, ",")) d.push_back(atoi(t));
@@ -42,6 +43,11 @@ int main(int argc, char **argv)
         }
     for (float c : sp.cost_matrix()) { unsigned u; memcpy(&u, &c, 4); fprintf(fp, "%08x ", u); }
     fprintf(fp, "\n");
+    fclose(fp);
+    fp = fopen((std::string(argv[8]) + ".shards").c_str(), "w");
+    if (!fp) return 5;
+    int d = 0;
+    for (const ACS_Rank::ShardReport &r : sp.lastShards()) fprintf(fp, "shard %d %d %d %d %d %lld\n", d++, r.device, r.pairs, r.slots, r.batches, r.weight);
     fclose(fp);
     return 0;
 }

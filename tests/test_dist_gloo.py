@@ -92,3 +92,29 @@ def test_synth_grid_matches_oracle_generator():
         assert np.array_equal(free, og.free) and np.array_equal(cx, og.cx) and p == 1.0 and wall == 0
     ids = synth.synth_weld_points(free, 48, 8)
     assert len(set(ids.tolist())) == 8 and np.all(free[ids] == 1)
+
+
+def test_pairs_are_dealt_longest_first_over_end_point_groups():
+    """deal_pairs (the rule of the drop-in C++ pair loop): every pair exactly once, loads balanced, whole end-point groups
+    per rank while there are enough of them, longest searches first within a rank."""
+    import numpy as np
+    rs = np.random.RandomState(3)
+    P = 64
+    pts = rs.randint(0, 256, (P, 3))
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    w = [1 + int(np.abs(pts[i] - pts[j]).sum()) for i, j in pairs]
+    for world in (1, 2, 3, 8):
+        shards, load = wd.deal_pairs(pairs, w, world)
+        assert sorted(k for sh in shards for k in sh) == list(range(len(pairs)))
+        assert load == [sum(w[k] for k in sh) for sh in shards]
+        assert max(load) <= 1.05 * (sum(w) / world), (world, load)          # 63 groups over <= 8 ranks balance to a few percent
+        for sh in shards:                                                       # whole groups: an end point lives on one rank
+            ends = {pairs[k][1] for k in sh}
+            assert all((pairs[k][1] in ends) == (k in sh) for k in range(len(pairs)))
+            assert w[sh[0]] == max(w[k] for k in sh)                            # the longest search of the rank leads
+    # few points: single pairs are dealt, loads differ by at most one search
+    pairs5 = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+    w5 = [3, 9, 4, 7, 5, 8, 2, 6, 1, 10]
+    shards, load = wd.deal_pairs(pairs5, w5, 3)
+    assert sorted(k for sh in shards for k in sh) == list(range(10)) and max(load) - min(load) <= max(w5)
+    assert wd.deal_pairs(pairs5, w5, 3) == (shards, load)

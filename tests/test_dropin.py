@@ -114,20 +114,36 @@ def test_dropin_pipeline_dev_mode_is_deterministic_and_sane():
 @pytest.mark.gpu
 def test_pair_loop_sharded_over_contexts_is_shard_invariant():
     """searchBestPathOfPoints' pair loop (ACSRank_3D.hpp:472-499) on one, two and three contexts -- host threads, a
-    wa_ctx + grid replica + solver each, pairs dealt round-robin, stream key = global pair index -- gives the same
-    costs and the same paths, bit for bit.  (One GPU here: an ordinal listed twice means two contexts on it.)"""
+    wa_ctx + grid replica + solver each, pairs dealt longest-first to the least loaded shard, stream key = global pair index
+    -- gives the same costs and the same paths, bit for bit, with three slots per shard or with the slot count sized by
+    rule (free memory, whole batches).  (One GPU here: an ordinal listed twice means two contexts on it.)"""
     libdir = os.path.dirname(_lib.LIB_PATH)
     exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
     r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
                         os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
-    outs = {}
-    for devs in ("0", "0,0", "0,0,0", "all"):
-        out = "/tmp/weldacs_shard_%s.txt" % devs.replace(",", "_")
-        rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", devs, out],
+    outs, shards = {}, {}
+    for devs, slots in (("0", 3), ("0,0", 3), ("0,0,0", 3), ("all", 3), ("0", 0), ("0,0,0", 0), ("0,0,0,0,0,0,0,0", 0)):
+        out = "/tmp/weldacs_shard_%s_%d.txt" % (devs.replace(",", "_"), slots)
+        rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", devs, out, str(slots)],
                             capture_output=True, text=True)
         assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
-        outs[devs] = open(out, "rb").read()
-    assert outs["0"].count(b"pair ") == 10 and b"7f800000" not in outs["0"]      # 10 finite pair costs
-    assert outs["0"] == outs["0,0"] == outs["0,0,0"] == outs["all"]
+        outs[(devs, slots)] = open(out, "rb").read()
+        shards[(devs, slots)] = [[int(v) for v in l.split()[1:]] for l in open(out + ".shards")]
+    ref = outs[("0", 3)]
+    assert ref.count(b"pair ") == 10 and b"7f800000" not in ref      # 10 finite pair costs
+    for k, v in outs.items():
+        assert v == ref, k                                             # 1, 2, 3, 8 contexts; 3 slots or sized by rule
+    # dealing: every pair exactly once, longest-first to the least loaded shard => weights within one search of each other
+    for k, sh in shards.items():
+        assert sum(r[2] for r in sh) == 10, (k, sh)
+        assert all(r[4] == -(-r[2] // r[3]) for r in sh), (k, sh)     # batches = ceil(pairs / slots)
+    one = shards[("0", 0)][0]
+    assert one[2] == 10 and one[3] == 10 and one[4] == 1               # sized by rule: all ten searches in ONE batch
+    three = shards[("0,0,0", 0)]
+    assert sorted(r[2] for r in three) == [3, 3, 4] and all(r[4] == 1 for r in three)
+    w = [r[5] for r in three]
+    longest = max(r[5] for r in shards[("0,0,0,0,0,0,0,0", 0)])      # eight shards, ten searches: the heaviest shard holds 1-2 searches
+    assert max(w) - min(w) <= longest
+    assert len(shards[("0,0,0,0,0,0,0,0", 0)]) == 8

@@ -1,0 +1,53 @@
+"""Shard sizing for the pair loop (SURVEY 8(e) partitioning; ACSRank_3D.hpp:472-499 runs the searches one after another):
+wa_acs_memory_estimate against what the allocator really hands out, and the slot rule at BASELINE config C5's shape."""
+import numpy as np
+import pytest
+
+from welding_robot_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("lazy,colony,nb", [(True, 24, 6), (False, 24, 6), (False, 256, 6), (False, 64, 26)])
+def test_memory_estimate_matches_the_allocator(ctx, lazy, colony, nb):
+    n = 96
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=3, occ_prob=0.1)
+    g = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    per_slot, per_field, fixed = api.memory_estimate(g, colony, 0, nb, lazy)
+    for slots in (2, 9):
+        ctx.sync()
+        before, _ = ctx.memory_info()
+        s = api.AcsSolver(ctx, g, n_slots=slots, max_colony=colony, neighbourhood=nb, lazy=lazy)
+        ctx.sync()
+        after, _ = ctx.memory_info()
+        used = before - after
+        want = slots * per_slot + min(slots, 4) * per_field + fixed
+        # the allocator rounds every block up (2 MiB granules): the estimate must not be below 90 % nor above 103 % of the truth
+        assert 0.90 * used <= want <= 1.03 * used + (64 << 20), (slots, used, want)
+        s.close()
+    g.close()
+
+
+def test_slot_rule_at_c5_shape(ctx):
+    """256^3, 24 ants, 2 016 searches over 63 end points on ONE device: nine whole batches of 224 -- the measured optimum
+     -- rather than 8 x 252 (past the footprint where the walk slows) or 224 x 9 with a remainder."""
+    n = 256
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.1)
+    g = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    fr, total = ctx.memory_info()
+    if fr < 250e9:
+        pytest.skip("less than 250 GB free on this device")
+    slots, batches = api.pair_slots_by_rule(ctx, g, 24, 2016, 63, 150)
+    assert (slots, batches) == (224, 9), (slots, batches)
+    # 8 devices: 252 searches per shard fit one device's limit? no: two whole batches of 126
+    assert api.pair_slots_by_rule(ctx, g, 24, 252, 8, 150) == (126, 2)
+    # a small job is one batch
+    assert api.pair_slots_by_rule(ctx, g, 24, 10, 4, 150) == (10, 1)
+    g.close()

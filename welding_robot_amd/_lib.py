@@ -54,6 +54,7 @@ SYMBOLS = {
     "wa_acs_create_nb": (C.c_int, [_V, _V, _I, _I, _I64, _I, C.POINTER(_V)]),
     "wa_acs_create_lazy": (C.c_int, [_V, _V, _I, _I, _I64, C.POINTER(_V)]),
     "wa_acs_destroy": (None, [_V]),
+    "wa_acs_memory_estimate": (C.c_int, [_V, _I, _I64, _I, _I, _P, _P, _P]),
     "wa_acs_init_pheromone": (C.c_int, [_V, _I, _F]),
     "wa_acs_reset_pheromone": (C.c_int, [_V, _I, _F]),
     "wa_acs_srand": (C.c_int, [_V, C.c_uint32]),

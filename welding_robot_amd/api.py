@@ -281,6 +281,28 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_evaporate(self.h, slot, C.c_float(rho), repeats))
 
 
+def memory_estimate(grid, max_colony, path_capacity=0, neighbourhood=6, lazy=False):
+    """(bytes per slot, bytes per heuristic field, fixed bytes) of a solver of this shape (wa_acs_memory_estimate)"""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    grid.ctx.check(grid.ctx.lib.wa_acs_memory_estimate(grid.h, max_colony, path_capacity, neighbourhood, 1 if lazy else 0,
+                                                       C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True):
+    """Concurrent pair searches for `n_pairs` searches on this device -- the rule of the drop-in ACS_Rank::slots_for
+    (welding_robot_amd/include/core/ACSRank_3D.hpp): 3/4 of the free memory but at most ~200 GB of fields, at most three
+    rounds of resident walk blocks, then whole batches of equal size.  Returns (slots, batches)."""
+    per_slot, per_field, fixed = memory_estimate(grid, colony, 0, 6, lazy)
+    per_slot += 20 * max_iteration
+    free, _ = ctx.memory_info()
+    fields = min(max(4, n_ends), 8)
+    cap = (min(free // 4 * 3, int(200e9)) - fixed - fields * per_field) // per_slot
+    cap = max(1, min(cap, max(1, 3 * 2048 // colony)))
+    batches = -(-n_pairs // cap)
+    return -(-n_pairs // batches), batches
+
+
 class Comm:
     """wa_comm: RCCL communicator behind the C ABI (csrc/host_comm.inc) -- the global-best exchange of the multi-GPU path.
     Rank 0 makes the id (Comm.unique_id()), the caller ships the 128 bytes to the other ranks."""

@@ -27,6 +27,8 @@ foreach(src ${WELDACS_USER_SOURCE})
 endforeach()
 include_directories(BEFORE ${WELDACS}/include ${WELDACS}/welding_robot_amd/include)   # weldacs.h, core/*.hpp
 add_executable(${PROJECT_NAME} ${WELDACS_SHADOW_SOURCE})
-target_link_libraries(${PROJECT_NAME} ${WELDACS}/welding_robot_amd/lib/libweldacs.so)
+# the drop-in ACS_Rank runs one host thread per device shard (std::thread)
+find_package(Threads REQUIRED)
+target_link_libraries(${PROJECT_NAME} ${WELDACS}/welding_robot_amd/lib/libweldacs.so Threads::Threads)
 # main.cpp itself still includes matplotlibcpp.h (main.cpp:2), so Python3/NumPy stay for the application shell;
 # the planning headers no longer need them (define WELDACS_WITH_MATPLOTLIB to keep plot_grid_map()/plot_path()).

@@ -15,8 +15,34 @@ def env_rank():
 
 
 def shard_problems(n_problems, rank, world):
-    """round-robin problem index -> rank (pairs have similar cost; LPT is a later refinement)"""
+    """round-robin problem index -> rank: for problems of equal cost (C4's one search per GPU, multi-start replicas)"""
     return list(range(rank, n_problems, world))
+
+
+def deal_pairs(pairs, weights, world):
+    """Pair searches -> ranks, longest-processing-time-first (the rule of the drop-in ACS_Rank, ACSRank_3D.hpp drop-in
+    searchBestPathOfPoints): a search costs about as much as its walks are long, i.e. grows with the Manhattan distance of
+    its two points.  Units sorted by weight, each to the least loaded rank; a unit is an END-POINT GROUP (all pairs (i, j)
+    with the same j share one heuristic field on the device) while there are >= 4 groups per rank, a single pair otherwise.
+    Within a rank: groups side by side, the group with the longest search first and the longest search first inside a group
+    (the partly filled last batch holds the shortest searches).  Returns (per-rank lists of pair indices, per-rank load)."""
+    n_points = 1 + max((j for _, j in pairs), default=0)
+    if world > 1 and n_points - 1 >= 4 * world:
+        units = [[k for k, (_, j) in enumerate(pairs) if j == e] for e in range(n_points)]
+    else:
+        units = [[k] for k in range(len(pairs))]
+    order = sorted(((-sum(weights[k] for k in u), i) for i, u in enumerate(units) if u))
+    shards, load = [[] for _ in range(world)], [0] * world
+    for negw, i in order:
+        d = min(range(world), key=lambda r: (load[r], r))
+        shards[d] += units[i]
+        load[d] -= negw
+    for sh in shards:
+        gmax = {}
+        for k in sh:
+            gmax[pairs[k][1]] = max(gmax.get(pairs[k][1], 0), weights[k])
+        sh.sort(key=lambda k: (-gmax[pairs[k][1]], pairs[k][1], -weights[k], k))
+    return shards, load
 
 
 def per_rank_workload(rank, grid_seed=2024, rng_seed=12345):

@@ -19,6 +19,7 @@
 #ifndef _ACS_3D_HPP
 #define _ACS_3D_HPP
 #include <assert.h>
+#include <stdlib.h>
 #include <time.h>
 
 #include <algorithm>
@@ -121,7 +122,12 @@ public:
     void setNeighbourhood(int n) { neighbourhood = n; }
     void setLazyEvaporation(bool b) { lazy = b; }
     void setGraphFileCompat(bool b) { graph_compat = b; }
+    // pair searches in flight per device.  Default 0 = sized per shard: as many as the device's free memory (wa_ctx_memory_info,
+    // wa_acs_memory_estimate) and the measured footprint limit allow, then evened out over whole batches
     void setConcurrentPairs(int n) { concurrent_pairs = n; }
+    // what the last searchBestPathOfPoints did per shard (device, pairs, concurrent slots, batches, summed Manhattan length)
+    struct ShardReport { int device; int pairs; int slots; int batches; long long weight; };
+    const std::vector<ShardReport> &lastShards() const { return shard_report; }
     // The pair loop (:472-499) is a loop over independent searches: in DEV mode it is sharded round-robin over
     // these devices, one host thread + one wa_ctx (+ a replica of the grid) per entry.  Every pair keeps its GLOBAL
     // index as stream key, so the cost matrix and the paths do not depend on the number of shards.  Default: every
@@ -186,11 +192,16 @@ public:
         p.rng_mode = rng_mode;
         p.seed = seed;
         std::vector<float> order_costs;
-        // ---- the searches: one shard per device (DEV mode), the primary context's solver is shard 0
+        // ---- the searches: one shard per device (DEV mode).  Shard 0 is the primary context (weldacs_dropin::context()), so the
+        // primary's ordinal leads the list and the remaining visible devices follow
         std::vector<int> devs;
         if (rng_mode == WA_RNG_DEV) {
             if (devices_set) devs = devices;
-            else for (int d = 0, n = wa_device_count(); d < n; d++) devs.push_back(d);
+            else {
+                const int prim = weldacs_dropin::device_ordinal();
+                devs.push_back(prim);
+                for (int d = 0, n = wa_device_count(); d < n; d++) if (d != prim) devs.push_back(d);
+            }
         }
         if (devs.size() > pairs.size()) devs.resize(pairs.size());
         if (devs.empty()) devs.push_back(weldacs_dropin::device_ordinal());
@@ -198,14 +209,62 @@ public:
         std::vector<PairResult> res(pairs.size());
         std::vector<int> shard_rc(D, WA_OK);
         std::vector<std::string> shard_err(D);
+        // Dealing: a search costs about as much as its walks are long, i.e. grows with the Manhattan distance of
+        // its two points (in voxel steps).  Longest-processing-time-first: units sorted by weight, each to the least loaded
+        // device.  A unit is an END-POINT GROUP (all pairs (i, j) with the same j: they share one heuristic field on the device,
+        // ACSRank_3D.hpp:151-154, and its cache lines) while there are enough groups to balance (>= 4 per device), a single
+        // pair otherwise.  No result depends on the dealing: every search draws from the stream of its GLOBAL pair index.
+        std::vector<long long> wgt(pairs.size());
+        for (size_t k = 0; k < pairs.size(); k++) {
+            const int64_t a = ids[pairs[k].first], b = ids[pairs[k].second];
+            const int64_t nxy = (int64_t)rangeX * rangeY;
+            wgt[k] = 1 + llabs(a / nxy - b / nxy) + llabs((a / rangeX) % rangeY - (b / rangeX) % rangeY) + llabs(a % rangeX - b % rangeX);
+        }
+        std::vector<std::vector<size_t>> shard_pairs(D);
+        std::vector<long long> load(D, 0);
+        {
+            std::vector<std::vector<size_t>> units;
+            if (D > 1 && point_num - 1 >= 4 * D) {
+                units.resize(point_num);
+                for (size_t k = 0; k < pairs.size(); k++) units[pairs[k].second].push_back(k);
+            } else {
+                for (size_t k = 0; k < pairs.size(); k++) units.push_back(std::vector<size_t>(1, k));
+            }
+            std::vector<std::pair<long long, size_t>> order;   // (-weight, unit): heaviest first, ties by index
+            for (size_t u = 0; u < units.size(); u++) {
+                long long w = 0;
+                for (size_t k : units[u]) w += wgt[k];
+                if (!units[u].empty()) order.push_back(std::make_pair(-w, u));
+            }
+            std::sort(order.begin(), order.end());
+            for (auto &o : order) {
+                int best_d = 0;
+                for (int d = 1; d < D; d++) if (load[d] < load[best_d]) best_d = d;
+                for (size_t k : units[o.second]) shard_pairs[best_d].push_back(k);
+                load[best_d] -= o.first;
+            }
+        }
+        // Within a shard: end-point groups side by side (one heuristic field each), the group with the longest search first and
+        // the longest search first inside a group, so that the partly filled last batch holds the shortest searches
+        for (int d = 0; d < D; d++) {
+            std::vector<size_t> &mine = shard_pairs[d];
+            if (rng_mode == WA_RNG_REF) { std::sort(mine.begin(), mine.end()); continue; }   // the reference's order (one libc stream)
+            std::vector<long long> gmax(point_num, 0);
+            for (size_t k : mine) gmax[pairs[k].second] = std::max(gmax[pairs[k].second], wgt[k]);
+            std::sort(mine.begin(), mine.end(), [&](size_t a, size_t b) {
+                const int ea = pairs[a].second, eb = pairs[b].second;
+                if (ea != eb) return gmax[ea] != gmax[eb] ? gmax[ea] > gmax[eb] : ea < eb;
+                return wgt[a] != wgt[b] ? wgt[a] > wgt[b] : a < b;
+            });
+        }
+        shard_report.assign(D, ShardReport());
+        std::vector<int> shard_slots(D, 1);
         auto run_shard = [&](int d, wa_ctx *ctx, wa_acs *sv) {
-            const int batch = rng_mode == WA_RNG_REF ? 1 : slots;
-            std::vector<size_t> mine;
-            for (size_t k = (size_t)d; k < pairs.size(); k += (size_t)D) mine.push_back(k);
-            // searches of one batch that end in the same point share one heuristic field on the device (wa_acs_begin): run them
-            // side by side.  The order does not change any result (every search draws from the stream of its global pair index).
-            if (rng_mode != WA_RNG_REF)
-                std::stable_sort(mine.begin(), mine.end(), [&](size_t a, size_t b) { return pairs[a].second < pairs[b].second; });
+            const int batch = rng_mode == WA_RNG_REF ? 1 : shard_slots[d];
+            const std::vector<size_t> &mine = shard_pairs[d];
+            ShardReport &rep = shard_report[d];
+            rep.device = devs[d]; rep.pairs = (int)mine.size(); rep.slots = batch; rep.weight = load[d];
+            rep.batches = (int)((mine.size() + batch - 1) / batch);
             for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
                 int nb = (int)std::min<size_t>(batch, mine.size() - b0);
                 std::vector<int64_t> s0(nb), e0(nb);
@@ -225,6 +284,16 @@ public:
                 if (rc != WA_OK) { shard_rc[d] = rc; shard_err[d] = wa_last_error(ctx); return; }
             }
         };
+        // slots of shard 0 (the others are sized on their own device when their context exists); the primary's solver is rebuilt
+        // if its size changed
+        shard_slots[0] = rng_mode == WA_RNG_REF ? 1 : slots_for(weldacs_dropin::context(), predict_path_len, (int)shard_pairs[0].size(), shard_pairs[0], pairs);
+        if (rng_mode != WA_RNG_REF && shard_slots[0] != slots) {
+            wa_acs_destroy(solver); solver = NULL;
+            slots_override = shard_slots[0];
+            int rc = make_solver(weldacs_dropin::context(), device_grid(), predict_path_len, &solver);
+            slots_override = 0;
+            if (rc != WA_OK) { printf("[ACS 3D] %s\n", wa_last_error(weldacs_dropin::context())); last_status = rc; return; }
+        }
         if (D == 1) {
             run_shard(0, weldacs_dropin::context(), solver);
         } else {
@@ -245,7 +314,12 @@ public:
             for (int d = 1; d < D; d++) {
                 int rc = wa_ctx_create(devs[d], &cs[d]);
                 if (rc == WA_OK) rc = wa_grid_from_occupancy(cs[d], fr.data(), rangeX, rangeY, rangeZ, ax.data(), ay.data(), az.data(), precision, wall, &gs[d]);
-                if (rc == WA_OK) rc = make_solver(cs[d], gs[d], predict_path_len, &ss[d]);
+                if (rc == WA_OK) {   // sized on the shard's own device, which may be shared with another shard
+                    shard_slots[d] = slots_for(cs[d], predict_path_len, (int)shard_pairs[d].size(), shard_pairs[d], pairs);
+                    slots_override = shard_slots[d];
+                    rc = make_solver(cs[d], gs[d], predict_path_len, &ss[d]);
+                    slots_override = 0;
+                }
                 if (rc != WA_OK) { shard_rc[d] = rc; shard_err[d] = cs[d] ? wa_last_error(cs[d]) : "wa_ctx_create failed"; }
             }
             std::vector<std::thread> th;
@@ -261,6 +335,9 @@ public:
         }
         for (int d = 0; d < D; d++)
             if (shard_rc[d] != WA_OK) { printf("[ACS 3D] shard %d (device %d): %s\n", d, devs[d], shard_err[d].c_str()); last_status = shard_rc[d]; return; }
+        for (int d = 0; d < D && rng_mode == WA_RNG_DEV; d++)
+            printf("[ACS 3D] shard %d: device %d, %d pair searches in %d batch(es) of up to %d, summed Manhattan length %lld\n", d,
+                   shard_report[d].device, shard_report[d].pairs, shard_report[d].batches, shard_report[d].slots, shard_report[d].weight);
         // ---- gather in the reference's pair order (`best` keeps its previous path when no ant arrived, Q9)
         for (size_t k = 0; k < pairs.size(); k++) {
             const int i = pairs[k].first, j = pairs[k].second;
@@ -353,7 +430,8 @@ private:
     bool devices_set = false;
     wa_acs *solver = NULL;
     int slots = 1;
-    int rng_mode = WA_RNG_DEV, max_iteration = 150, fixed_colony = 0, concurrent_pairs = 16, neighbourhood = 6;
+    int rng_mode = WA_RNG_DEV, max_iteration = 150, fixed_colony = 0, concurrent_pairs = 0, neighbourhood = 6, slots_override = 0;
+    std::vector<ShardReport> shard_report;
     bool lazy = true;
     uint64_t seed = 1;
     bool seeded = false, graph_compat = false;
@@ -379,14 +457,48 @@ private:
         printf("[ACS 3D] Created %d nodes, node cubiod [x: %d, y: %d, z: %d]\r\n", size_of_map(), rangeX, rangeY, rangeZ);
         return true;
     }
+    int colony_of(float predict) const
+    {
+        int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
+        return colony < 1 ? 1 : colony;
+    }
+    bool lazy_ok(int colony) const { return lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64; }
+    // Concurrent pair searches of a shard with `n_pairs` searches.  Upper bound from memory: 3/4 of what the device has free
+    // (ctx == NULL: the primary context), and never more than ~200 GB of fields -- past that footprint the walk's random record
+    // loads slow down (measured on BASELINE config C5: 224 slots of 0.85 GB run 2 016 searches in 0.57 s, 252 in 1.0 s).  The
+    // heuristic pool holds one field per distinct end point of a batch (at most 8 are assumed here: the shard's order keeps
+    // end-point groups together).  Then whole batches: ceil(n / cap) batches of equal size instead of full ones + a remainder.
+    int slots_for(wa_ctx *ctx, float predict, int n_pairs, const std::vector<size_t> &mine, const std::vector<std::pair<int, int>> &pairs)
+    {
+        if (n_pairs < 1) return 1;
+        if (concurrent_pairs > 0) return std::min(concurrent_pairs, n_pairs);
+        if (!ctx) ctx = weldacs_dropin::context();
+        const int colony = colony_of(predict);
+        int64_t per_slot = 0, per_field = 0, fixed = 0, free_b = 0, total_b = 0;
+        if (wa_acs_memory_estimate(device_grid(), colony, 0, neighbourhood, lazy_ok(colony) ? 1 : 0, &per_slot, &per_field, &fixed) != WA_OK ||
+            wa_ctx_memory_info(ctx, &free_b, &total_b) != WA_OK || per_slot <= 0) return std::min(16, n_pairs);
+        per_slot += 20 * (int64_t)max_iteration;                      // the per-generation trace
+        std::vector<int> ends;
+        for (size_t k : mine) if (std::find(ends.begin(), ends.end(), pairs[k].second) == ends.end()) ends.push_back(pairs[k].second);
+        const int64_t fields = std::min<int64_t>(std::max<int64_t>(4, (int64_t)ends.size()), 8);
+        int64_t budget = std::min<int64_t>(free_b / 4 * 3, (int64_t)200e9) - fixed - fields * per_field;
+        int64_t cap = budget / per_slot;
+        // a launch of more walk blocks than three rounds of resident wavefronts (one per SIMD x 256 CUs x 4, two with a 2^12 hash)
+        // only queues: bound the slots by that too
+        cap = std::min<int64_t>(cap, std::max<int64_t>(1, (int64_t)3 * 2048 / colony));
+        if (cap < 1) cap = 1;
+        const int64_t batches = (n_pairs + cap - 1) / cap;
+        return (int)((n_pairs + batches - 1) / batches);
+    }
     // one solver for this grid on `ctx` (the primary context or a shard's)
     int make_solver(wa_ctx *ctx, wa_grid *g, float predict, wa_acs **out)
     {
-        int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
-        if (colony < 1) colony = 1;
-        slots = rng_mode == WA_RNG_REF ? 1 : std::max(1, concurrent_pairs);
-        const bool lazy_ok = lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64;
-        int rc = lazy_ok ? wa_acs_create_lazy(ctx, g, slots, colony, 0, out) : wa_acs_create_nb(ctx, g, slots, colony, 0, neighbourhood, out);
+        const int colony = colony_of(predict);
+        // (initFromGridMap builds the primary's solver before the pairs are known: one slot; the pair loop re-creates it at the
+        // shard's size)
+        const int want = rng_mode == WA_RNG_REF ? 1 : (slots_override > 0 ? slots_override : std::max(1, concurrent_pairs));
+        if (ctx == weldacs_dropin::context()) slots = want;
+        int rc = lazy_ok(colony) ? wa_acs_create_lazy(ctx, g, want, colony, 0, out) : wa_acs_create_nb(ctx, g, want, colony, 0, neighbourhood, out);
         if (rc == WA_OK) rc = wa_acs_init_pheromone(*out, -1, 1.0f);
         return rc;
     }
