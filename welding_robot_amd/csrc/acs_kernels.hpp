@@ -669,6 +669,25 @@ __device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const
     }
 }
 
+#ifdef WA_ANT_TIME
+#define WA_PHASE(i) do { if (slot == 0 && ant == 0 && threadIdx.x == 0 && D.dbg) atomicAdd(&D.dbg[i], (unsigned long long)__builtin_readcyclecounter()); } while (0)
+#else
+#define WA_PHASE(i) do { } while (0)
+#endif
+// every slot of the tabu hash := empty.  Eight 1-KB wave stores per trip (immediate offsets, no address arithmetic between them):
+// the 128 KB table of a lone search takes ~0.5 us instead of the 4.6 us of a store-per-trip loop (measured, tools/ant_time.py)
+__device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
+{
+    const int n16 = (1 << hash_log2) / 4, lane = threadIdx.x;
+    const int4 e = make_int4(-1, -1, -1, -1);
+    int i = lane;
+    for (; i + 7 * 64 < n16; i += 8 * 64) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) tab4[i + u * 64] = e;
+    }
+    for (; i < n16; i += 64) tab4[i] = e;
+}
+
 template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
@@ -734,9 +753,11 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
 
+    WA_PHASE(6);
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
-    for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
+    wa_tabu_clear(tab4, hash_log2);
     __builtin_amdgcn_wave_barrier();
+    WA_PHASE(7);
     if (prefix_words && st.len <= spill_at) {  // (a longer prefix goes straight to the spilled slow loop)
         // tabu set := the replayed prefix.  Distinct keys, no deletions: any insertion order gives a valid
         // open-addressing table, so the lanes insert concurrently with compare-and-swap on the slot.
@@ -813,9 +834,11 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (st.len >= fast_limit) break;
         }
         if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it
-    } else if (st.len < fast_limit && use_asm)
+    } else if (st.len < fast_limit && use_asm) {
+        WA_PHASE(8);
         wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
+    }
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
                                    rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
@@ -826,6 +849,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     } else if (!prefix_words && lane == 0) {
         path[0] = start;  // the slow loop reads the path back from memory
     }
+    WA_PHASE(9);
     if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
@@ -987,8 +1011,23 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     // the rejoin watch pays once the colony has settled on the best path (it costs a failed attempt every few steps while the
     // ants still explore): it is switched on when that path has not changed for a number of generations
     if (gen - c->tabu_gen < ((walk_flags >> 24) & 127)) walk_flags &= ~2;
+#ifdef WA_ANT_TIME   // diagnostic build (tools/ant_time.py): shader-clock ticks of every ant's block against its step count
+    const unsigned long long t0_ = __builtin_readcyclecounter();
+    if (slot == 0 && ant == 0 && threadIdx.x == 0 && D.dbg) atomicAdd(&D.dbg[5], t0_);
+#endif
     wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot);
+#ifdef WA_ANT_TIME
+    if (threadIdx.x == 0 && D.dbg) {
+        if (slot == 0 && ant == 0) atomicAdd(&D.dbg[10], (unsigned long long)__builtin_readcyclecounter());
+        const unsigned long long t = __builtin_readcyclecounter() - t0_;
+        const unsigned long long n = (unsigned long long)(D.antLen[(int64_t)slot * D.max_colony + ant] - 1);
+        atomicMax(&D.dbg[1], (t << 24) | n);        // the slowest ant: (ticks, steps)
+        atomicMax(&D.dbg[4], (n << 32) | t);        // the ant with the most steps: (steps, ticks)
+        atomicAdd(&D.dbg[2], t);
+        atomicAdd(&D.dbg[3], n);
+    }
+#endif
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -1891,7 +1930,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
-    for (int i = lane; i < (1 << hash_log2) / 4; i += 64) tab4[i] = make_int4(-1, -1, -1, -1);
+    wa_tabu_clear(tab4, hash_log2);
     __builtin_amdgcn_wave_barrier();
     if (r_node > 0) {   // deviated at best[r_node]: tabu set := the replayed prefix (distinct keys: concurrent CAS inserts)
         const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;

@@ -39,7 +39,140 @@
 #define WA_ASM_VMWAIT_LAZY_NONE "s_waitcnt vmcnt(3)\n"
 // -DWA_ASM_STAMPS (diagnostic builds, tools/walk_stamps_asm.py): s_memtime at six points of the step, differences summed in
 // s72..s77 (s70 = previous stamp); each stamp drains LDS and costs ~40 cycles: read the shares, not the totals
-#if defined(WA_ASM_STAMPS)
+// -DWA_ASM_SPAN_A=a -DWA_ASM_SPAN_B=b (diagnostic builds, tools/walk_spans.py): ONE pair of s_memtime per step, at points a and b of
+// the step (0 top, 1 after the LDS wait, 2 after the record wait, 3 before the masks, 4 before the sums, 5 after them, 6 after the
+// rare-event branch, 7 after the insert, 8 between record loads and probe, 9 after both, 10 end), nobody waits for them: the step's own
+// lgkmcnt(0) at the head of the NEXT step covers them, and the difference is summed there (s72).  a == b: the time between two
+// consecutive passes of that point = the whole step.  Two instructions per step instead of six draining stamps.
+#if defined(WA_ASM_SPAN_A)
+#define WA_ASM_STAMPS 1
+#define WA_ASM_STAMP(i) ""
+#define WA_ASM_SPAN_ACC "s_sub_u32 s64, s62, s60\n s_cmp_eq_u32 s60, 0\n s_cselect_b32 s64, 0, s64\n s_cmp_eq_u32 s62, 0\n s_cselect_b32 s64, 0, s64\n s_add_u32 s72, s72, s64\n" WA_ASM_SPAN_RESET
+#if WA_ASM_SPAN_A == WA_ASM_SPAN_B
+#define WA_ASM_SPAN_RESET ""
+#define WA_ASM_SPAN_AT "s_mov_b32 s60, s62\n s_memtime s[62:63]\n"
+#else
+#define WA_ASM_SPAN_RESET "s_mov_b32 s60, 0\n s_mov_b32 s62, 0\n"
+#endif
+#if WA_ASM_SPAN_A == 0 && WA_ASM_SPAN_B == 0
+#define WA_SPAN_0 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 0
+#define WA_SPAN_0 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 0
+#define WA_SPAN_0 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_0 ""
+#endif
+#if WA_ASM_SPAN_A == 1 && WA_ASM_SPAN_B == 1
+#define WA_SPAN_1 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 1
+#define WA_SPAN_1 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 1
+#define WA_SPAN_1 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_1 ""
+#endif
+#if WA_ASM_SPAN_A == 2 && WA_ASM_SPAN_B == 2
+#define WA_SPAN_2 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 2
+#define WA_SPAN_2 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 2
+#define WA_SPAN_2 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_2 ""
+#endif
+#if WA_ASM_SPAN_A == 3 && WA_ASM_SPAN_B == 3
+#define WA_SPAN_3 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 3
+#define WA_SPAN_3 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 3
+#define WA_SPAN_3 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_3 ""
+#endif
+#if WA_ASM_SPAN_A == 4 && WA_ASM_SPAN_B == 4
+#define WA_SPAN_4 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 4
+#define WA_SPAN_4 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 4
+#define WA_SPAN_4 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_4 ""
+#endif
+#if WA_ASM_SPAN_A == 5 && WA_ASM_SPAN_B == 5
+#define WA_SPAN_5 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 5
+#define WA_SPAN_5 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 5
+#define WA_SPAN_5 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_5 ""
+#endif
+#if WA_ASM_SPAN_A == 6 && WA_ASM_SPAN_B == 6
+#define WA_SPAN_6 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 6
+#define WA_SPAN_6 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 6
+#define WA_SPAN_6 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_6 ""
+#endif
+#if WA_ASM_SPAN_A == 7 && WA_ASM_SPAN_B == 7
+#define WA_SPAN_7 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 7
+#define WA_SPAN_7 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 7
+#define WA_SPAN_7 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_7 ""
+#endif
+#if WA_ASM_SPAN_A == 8 && WA_ASM_SPAN_B == 8
+#define WA_SPAN_8 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 8
+#define WA_SPAN_8 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 8
+#define WA_SPAN_8 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_8 ""
+#endif
+#if WA_ASM_SPAN_A == 9 && WA_ASM_SPAN_B == 9
+#define WA_SPAN_9 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 9
+#define WA_SPAN_9 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 9
+#define WA_SPAN_9 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_9 ""
+#endif
+#if WA_ASM_SPAN_A == 10 && WA_ASM_SPAN_B == 10
+#define WA_SPAN_10 WA_ASM_SPAN_AT
+#elif WA_ASM_SPAN_A == 10
+#define WA_SPAN_10 "s_memtime s[60:61]\n"
+#elif WA_ASM_SPAN_B == 10
+#define WA_SPAN_10 "s_memtime s[62:63]\n"
+#else
+#define WA_SPAN_10 ""
+#endif
+#define WA_ASM_COUNT_COLL "s_add_u32 s73, s73, 1\n"
+#define WA_ASM_COUNT_EVENT "s_add_u32 s74, s74, 1\n"
+#else
+#define WA_ASM_SPAN_ACC ""
+#define WA_ASM_COUNT_COLL ""
+#define WA_ASM_COUNT_EVENT ""
+#define WA_SPAN_0 ""
+#define WA_SPAN_1 ""
+#define WA_SPAN_2 ""
+#define WA_SPAN_3 ""
+#define WA_SPAN_4 ""
+#define WA_SPAN_5 ""
+#define WA_SPAN_6 ""
+#define WA_SPAN_7 ""
+#define WA_SPAN_8 ""
+#define WA_SPAN_9 ""
+#define WA_SPAN_10 ""
+#endif
+#if defined(WA_ASM_SPAN_A)
+#elif defined(WA_ASM_STAMPS)
 #define WA_ASM_STAMP(i) "s_memtime s[60:61]\n" "s_waitcnt lgkmcnt(0)\n" "s_sub_u32 s62, s60, s70\n" "s_add_u32 s" #i ", s" #i ", s62\n" "s_mov_b32 s70, s60\n"
 #else
 #define WA_ASM_STAMP(i) ""
@@ -113,33 +246,14 @@
     "v_mov_b32 %[hio], " CH "\n"                                                                                  \
     "s_mov_b32 %[code], 4\n"                                                                                      \
     "s_branch Lwa_out%=\n"
-#define WA_ASM_STEP(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_NONE, W)
-#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_WATCH, W)
-#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_NONE, W)
-#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_WATCH, W)
-#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ, W)                                \
-    WA_ASM_WARM_ADDR_##W                                          /* (s40 = cur * 24 since the previous step's tail) */ \
-    WA_ASM_STAMP(72)                                                                                              \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    WA_ASM_STAMP(73)                                                                                              \
-    REJ(X)                                                        /* once per step: a re-evaluation (collision, block boundary) enters below */ \
-    "Lwa_redo_" X "%=:\n"                                                                                         \
-    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
-    "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
-    VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
-    WA_ASM_STAMP(74)                                                                                              \
-    "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
-    INFO(CP, CH, CS, X)                                                                                           \
-    WA_ASM_WARM0_##W                                              /* records two hops away: touched, never waited for */ \
-    WA_ASM_WARM1_##W                                                                                              \
-    INFO2(X)                                                                                                      \
+#define WA_ASM_MASKS(X)                                                                                           \
     "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
     "s_cbranch_scc1 Lwa_coll_" X "%=\n"                                                                           \
     "s_and_b64 s[50:51], s[50:51], vcc\n"                         /* ... and not visited (:145) */                \
-    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active block */                   \
-    "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
-    "v_readlane_b32 s42, %[ub], m0\n"                             /* this step's uniform draw (:169) */           \
-    "v_add_u32 v85, %[cur], v69\n"                                /* candidate path words: (cur + d_k) | k << 29 */ \
+    "s_and_b64 s[52:53], s[50:51], s[54:55]\n"                    /* ... in the active block */
+// the two ordered fp32 sums (:170 total, ascending k; :178 prob_sum, descending k) as 5 + 5 DPP row shifts; a DPP read of a
+// register written by the previous VALU instruction needs two wait states: the other chain's add + one s_nop
+#define WA_ASM_SUMS                                                                                               \
     "v_add_f32_dpp v80, v78, v78" WA_ASM_DPP_C                                                                    \
     "v_add_f32_dpp v79, v78, v78" WA_ASM_DPP_T                                                                    \
     "s_nop 0\n"                                                                                                   \
@@ -153,7 +267,55 @@
     "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
     "s_nop 0\n"                                                                                                   \
     "v_add_f32_dpp v80, v80, v78" WA_ASM_DPP_C                                                                    \
-    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T                                                                    \
+    "v_add_f32_dpp v79, v79, v78" WA_ASM_DPP_T
+#define WA_ASM_NEXT_LOADS(CP, CH, CS, HEAD)                                                                       \
+    "s_mul_i32 s40, %[cur], 24\n"                                 /* records of the new voxel's six neighbours: needed by the step after */ \
+    "v_add_u32 v82, s40, v65\n"                                   /* the next one; they go where this step's records were */ \
+    "global_load_dword " CP ", v82, %[pher]\n"                                                                    \
+    "global_load_dword " CH ", v82, %[heur]\n"                                                                    \
+    HEAD(CS)
+#define WA_ASM_NEXT_PROBE                                                                                         \
+    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
+    "v_add_u32 v77, s41, v67\n"                                                                                   \
+    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
+    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
+    "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
+    "v_add_u32 v76, %[cur], v68\n"
+// the probe goes first: its LDS round trip (~50 cycles) then runs under the record loads' issue instead of in front of the next
+// step's head (measured, tools/walk_ab.py: -1 % on the step)
+#define WA_ASM_NEXT(CP, CH, CS, HEAD) WA_ASM_NEXT_PROBE WA_SPAN_8 WA_ASM_NEXT_LOADS(CP, CH, CS, HEAD)
+#define WA_ASM_STEP(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_NONE, W)
+#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_WATCH, W)
+#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_NONE, W)
+#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_WATCH, W)
+#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ, W)                                \
+    WA_SPAN_0                                                                                                     \
+    WA_ASM_WARM_ADDR_##W                                          /* (s40 = cur * 24 since the previous step's tail) */ \
+    WA_ASM_STAMP(72)                                                                                              \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    WA_ASM_SPAN_ACC                                                                                               \
+    WA_SPAN_1                                                                                                     \
+    WA_ASM_STAMP(73)                                                                                              \
+    REJ(X)                                                        /* once per step: a re-evaluation (collision, block boundary) enters below */ \
+    "Lwa_redo_" X "%=:\n"                                                                                         \
+    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
+    "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
+    VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
+    WA_SPAN_2                                                                                                     \
+    WA_ASM_STAMP(74)                                                                                              \
+    "v_cmp_lt_i32 s[50:51], -1, " CP "\n"                         /* sign clear: in bounds and free (:148) */     \
+    INFO(CP, CH, CS, X)                                                                                           \
+    WA_ASM_WARM0_##W                                              /* records two hops away: touched, never waited for */ \
+    WA_ASM_WARM1_##W                                                                                              \
+    INFO2(X)                                                                                                      \
+    WA_SPAN_3                                                                                                     \
+    WA_ASM_MASKS(X)                                                                                               \
+    "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
+    WA_SPAN_4                                                                                                     \
+    "v_readlane_b32 s42, %[ub], m0\n"                             /* this step's uniform draw (:169) */           \
+    "v_add_u32 v85, %[cur], v69\n"                                /* candidate path words: (cur + d_k) | k << 29 */ \
+    WA_ASM_SUMS                                                                                                   \
+    WA_SPAN_5                                                                                                     \
     WA_ASM_STAMP(75)                                                                                              \
     "v_mul_f32 v81, s42, v79\n"                                   /* rnd = u * total (:170), valid in position 0 */ \
     "s_nop 0\n"                                                                                                   \
@@ -162,36 +324,31 @@
     "v_cmp_le_f32 vcc, s43, v80\n"                                /* prob_sum >= rnd (:178) */                    \
     "s_and_b64 s[56:57], vcc, s[52:53]\n"                                                                         \
     "s_cbranch_scc0 Lwa_rare_" X "%=\n"                           /* no candidate (:162), fall-through (:191), or a pending event */ \
+    WA_SPAN_6                                                                                                     \
     WA_ASM_STAMP(76)                                                                                              \
     "s_ff1_i32_b64 s45, s[56:57]\n"                               /* first hit scanning edge 5 -> 0 */            \
     "v_cmp_eq_u32 vcc, s45, v64\n"                                                                                \
     "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
     "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
     "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
+    WA_SPAN_7                                                                                                     \
     "s_lshl_b32 %[g8], s45, 3\n"                                  /* next active block = position of the pick (low 6 bits count) */ \
     "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
-    "s_mul_i32 s40, %[cur], 24\n"                                 /* records of the new voxel's six neighbours: needed by the step after */ \
-    "v_add_u32 v82, s40, v65\n"                                   /* the next one; they go where this step's records were */ \
-    "global_load_dword " CP ", v82, %[pher]\n"                                                                    \
-    "global_load_dword " CH ", v82, %[heur]\n"                                                                    \
-    HEAD(CS)                                                                                                      \
-    "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
-    "v_add_u32 v77, s41, v67\n"                                                                                   \
-    "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
-    "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
-    "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
-    "v_add_u32 v76, %[cur], v68\n"                                                                                \
+    WA_ASM_NEXT(CP, CH, CS, HEAD)                                                                                 \
+    WA_SPAN_9                                                                                                     \
     "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
     "s_add_i32 m0, m0, 1\n"                                                                                       \
     "s_and_b32 s46, m0, 63\n"                                                                                     \
     "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* block of 64 path words complete: event */    \
     "s_cmp_lg_u32 %[cur], %[end]\n"                                                                               \
     "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* arrived (:182): event */                     \
+    WA_SPAN_10                                                                                                    \
     WA_ASM_STAMP(77)
 // some lane's probe hit another key: advance those lanes along their chains, then evaluate the step again
 #define WA_ASM_COLL(X)                                                                                            \
     "Lwa_coll_" X "%=:\n"                                                                                         \
+    WA_ASM_COUNT_COLL                                                                                             \
     "s_mov_b64 s[58:59], exec\n"                                                                                  \
     "s_mov_b64 exec, s[48:49]\n"                                                                                  \
     "v_add_u32 v77, 4, v77\n"                                                                                     \
@@ -236,12 +393,17 @@
     "global_load_dword v73, v82, %[pher]\n"                                                                       \
     "global_load_dword v74, v82, %[heur]\n"
 #if defined(WA_ASM_STAMPS)
+#if defined(WA_ASM_SPAN_A)
+#define WA_ASM_STAMPS_INIT "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n" \
+                           "s_mov_b32 s60, 0\n s_mov_b32 s62, 0\n"
+#else
 #define WA_ASM_STAMPS_INIT "s_mov_b32 s72, 0\n s_mov_b32 s73, 0\n s_mov_b32 s74, 0\n s_mov_b32 s75, 0\n s_mov_b32 s76, 0\n s_mov_b32 s77, 0\n" \
                            "s_memtime s[60:61]\n s_waitcnt lgkmcnt(0)\n s_mov_b32 s70, s60\n"
+#endif
 #define WA_ASM_STAMPS_DUMP "v_mov_b32 v94, s72\n ds_write_b32 %[lc], v94 offset:1792\n v_mov_b32 v94, s73\n ds_write_b32 %[lc], v94 offset:2048\n" \
                            "v_mov_b32 v94, s74\n ds_write_b32 %[lc], v94 offset:2304\n v_mov_b32 v94, s75\n ds_write_b32 %[lc], v94 offset:2560\n" \
                            "v_mov_b32 v94, s76\n ds_write_b32 %[lc], v94 offset:2816\n v_mov_b32 v94, s77\n ds_write_b32 %[lc], v94 offset:3072\n"
-#define WA_ASM_STAMPS_CLOBBER "s60", "s61", "s62", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
+#define WA_ASM_STAMPS_CLOBBER "s60", "s61", "s62", "s63", "s64", "s70", "s72", "s73", "s74", "s75", "s76", "s77",
 #else
 #define WA_ASM_STAMPS_INIT ""
 #define WA_ASM_STAMPS_DUMP ""
@@ -253,6 +415,7 @@
     "s_mov_b32 %[code], 1\n"                                                                                      \
     "s_branch Lwa_out%=\n"                                                                                        \
     "Lwa_event%=:\n"                                                                                              \
+    WA_ASM_COUNT_EVENT                                                                                            \
     "s_mov_b32 %[code], 2\n"                                                                                      \
     "s_and_b32 s46, m0, 63\n"                                                                                     \
     "s_cbranch_scc1 Lwa_out%=\n"                   /* no complete block: it is the arrival (:182-186) */          \
