@@ -17,13 +17,15 @@ Rank 0 prints one JSON line: metric/value (whole-job generations/s), `roofline` 
 evaporation sweep and -- at N = 1 -- `cpu_baseline`: the reference's own loop (oracle/_ref/ref_harness,
 kind "reference") or the C oracle (kind "port") timed on this host on a bounded sample.
 
-roofline (the same at any --steps): after the timed region the sweep kernel itself, `k_evaporate`
-(ACSRank_3D.hpp:268-272: 48 B of algorithmic traffic per voxel), is launched 64 times on the library's own
-stream with per-dispatch HIP events (hipExtLaunchKernelGGL start/stop) at the BASELINE size 128^3 (two
-48 MiB buffers: inside the 256 MiB Infinity Cache) and at 256^3 (805 MB per launch: past it).  The headline
-`frac` is the 128^3 figure, `frac_256` stands beside it.  Inside the generation loop the sweep shares a
-launch with the latency-bound rank/mark blocks; that fused launch is reported separately (`fused_launch`,
->= 32 samples whatever --steps is) and is NOT the roofline figure.
+roofline: the launch of the timed loop that carries the evaporation sweep (ACSRank_3D.hpp:268-272: 48 B of
+algorithmic traffic per voxel) is `k_evap_rank_mark` -- 4096 sweep blocks + the latency-bound rank / mark blocks of the
+same generation.  Its launches are stamped per dispatch with HIP events on the library's own stream (hipExtLaunchKernelGGL
+start/stop) over the timed region; `achieved` = 48 N^3 / that average, `frac` against the 8 TB/s HBM3E peak.  At 128^3
+both 48 MiB buffers sit in the 256 MiB Infinity Cache, so beside it `sweep_alone` reports the sweep kernel itself
+(`k_evaporate`, 64 stamped launches after the timed region) at 128^3 and at 256^3 (805 MB per launch: past the cache).
+Extras after the timed region, outside `value`: `full_run` (the same search over BASELINE config 3's stated 500
+generations), `c5_full` (BASELINE config 5 at full size on this GPU), `walk_step` (time per general step of the walk
+against the issue floor of its assembled loop), `c5_pair_planning` (dense vs lazy evaporation, must agree).
 """
 import argparse
 import json
@@ -50,7 +52,7 @@ def parse():
     ap.add_argument("--cpu-gens", type=int, default=20, help="generations of the CPU baseline sample")
     ap.add_argument("--cost-check-gens", type=int, default=None, help="generations the CPU port replays for cost_check (default: all K)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=10)
+    ap.add_argument("--profile-every", type=int, default=10, help="stamp every n-th generation's launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary C5-shaped pair-planning measurement")
     ap.add_argument("--no-roofline-256", action="store_true", help="skip the 256^3 (past the Infinity Cache) sweep measurement")
     ap.add_argument("--workload-index", type=int, default=None,
@@ -133,12 +135,31 @@ def sweep_roofline(ctx, n, repeats=64):
             "achieved": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
 
 
+def _walk_loop_evidence():
+    """instructions per step from the ISA dump tools/walk_isa.py writes at build time, cycles per instruction and shader clock of
+    a lone wavefront from the issue-rate microbenchmark's committed output -- nothing of this is a constant in this file"""
+    import glob
+    import re
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "walk_loop_isa.txt")), reverse=True):
+        m = re.match(r"# instructions_per_step: (\d+)", open(f).readline())
+        if m:
+            out["instructions_per_step"], out["isa_file"] = int(m.group(1)), os.path.relpath(f, ROOT)
+            break
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "issue_rates.txt")), reverse=True):
+        m = re.search(r"v_add_f32 dependent\s+([\d.]+) ticks.*?=\s*([\d.]+) GHz", open(f).read())
+        if m:
+            out["cycles_per_instruction"], out["shader_clock_ghz"], out["issue_rates_file"] = float(m.group(1)), float(m.group(2)), os.path.relpath(f, ROOT)
+            break
+    return out
+
+
 def walk_step_extra(solver, p, ids, wl, generations=12):
     """What the exploratory generations are made of, measured after the timed region on a fresh identical search: a walk
     launch lasts as long as its slowest ant, so launch time / the longest walk of the generation = the time of one
-    general step of a lone wavefront (61 instructions at ~4.3 cycles of issue each + load issue + stalls).
-    `issue_floor_ns` is what 61 instructions alone would take at the measured 2.39 GHz shader clock -- the bound this
-    latency-bound kernel can be held against (it is neither an HBM nor an MFMA kernel)."""
+    general step of a lone wavefront.  `issue_floor_ns` = instructions per step (from the ISA dump of this build's loop) x
+    the issue cost of one instruction of a lone wavefront (microbenchmark): the bound this issue-bound kernel can be held
+    against (it is neither an HBM nor an MFMA kernel)."""
     import numpy as np
     solver.init_pheromone(1.0)
     solver.begin(p, ids[0], ids[1], streams=[wl["stream"]])
@@ -151,10 +172,71 @@ def walk_step_extra(solver, p, ids, wl, generations=12):
         ns.append(pr["walk"]["ms"] * 1e6 / max(int(lens.max()) - 1, 1))
     solver.profile(False, 1)
     step = float(np.median(ns))
-    floor = 61 * 4.3 / 2.39
-    return {"ns_per_step_of_the_longest_walk": step, "generations_sampled": generations, "instructions_per_step": 61,
-            "issue_floor_ns": floor, "frac_of_issue_floor": floor / step if step > 0 else 0.0,
-            "source": "walk launch time / max(ant steps) per generation; ISA in profiles/r02/walk_loop_isa.txt, issue rates in profiles/r02/issue_rates.txt"}
+    out = {"ns_per_step_of_the_longest_walk": step, "generations_sampled": generations,
+           "source": "walk launch time / max(ant steps) per generation"}
+    ev = _walk_loop_evidence()
+    out.update(ev)
+    if {"instructions_per_step", "cycles_per_instruction", "shader_clock_ghz"} <= set(ev):
+        floor = ev["instructions_per_step"] * ev["cycles_per_instruction"] / ev["shader_clock_ghz"]
+        out["issue_floor_ns"] = floor
+        out["frac_of_issue_floor"] = floor / step if step > 0 else 0.0
+    return out
+
+
+def full_run_extra(solver, params, ids, wl, n, gens=500):
+    """BASELINE config 3 at its stated length on the same grid: a fresh identical search, 500 generations end to end
+    (exploration, convergence, the converged regime).  Outside `value`; bounded (~25 ms of GPU time)."""
+    solver.profile(False, 1)
+    solver.init_pheromone(1.0)
+    solver.begin(params(gens, wl["rng_seed"]), ids[0], ids[1], streams=[wl["stream"]])
+    solver.ctx.sync()
+    solver.profile(True, 10)
+    t0 = time.perf_counter()
+    solver.run(gens)
+    solver.sync()
+    dt = time.perf_counter() - t0
+    pr = solver.profile_read()
+    solver.profile(False, 1)
+    cost, path, _ = solver.result()
+    tr = solver.trace()
+    fused_ms = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1)
+    return {"workload": "%d^3, %d generations of the same search (BASELINE config 3 as stated)" % (n, gens), "generations": gens,
+            "generations_per_s": gens / dt, "ms_total": dt * 1e3, "best_cost": float(cost), "path_nodes": int(len(path)),
+            "generation_of_last_improvement": int((tr["bestL"] != tr["bestL"][-1]).sum()),
+            "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()},
+            "in_loop_frac": 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None}
+
+
+def c5_full_extra(ctx):
+    """BASELINE config 5 at FULL size on this one GPU: 256^3 grid, 64 weld points, all 2 016 pair searches x 150 generations
+    (24 ants each, lazy evaporation, concurrent slots sized by the library's rule from free memory), then the 64-seam ACS-TSP order
+    from the in-memory matrix.  Solver creation (device allocation) is timed separately.  Outside `value`; bounded (a few s)."""
+    import importlib.util
+    import numpy as np
+    from welding_robot_amd import api, synth
+    spec = importlib.util.spec_from_file_location("plan_batch", os.path.join(ROOT, "examples", "plan_batch.py"))
+    pb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pb)
+    n, P, gens, seed = 256, 64, 150, 7
+    t0 = time.perf_counter()
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    pts = synth.synth_weld_points(free, n, P, seed=seed)
+    t_inputs = time.perf_counter() - t0
+    predict = float(24 / 0.35)
+    t0 = time.perf_counter()
+    cost, paths, mine = pb.plan(ctx, grid, pts, gens, predict, seed, 0, lazy=True)
+    ctx.sync()
+    t_pairs = time.perf_counter() - t0 - pb.plan.last_create_s
+    t0 = time.perf_counter()
+    tour = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=seed)
+    t_gtsp = time.perf_counter() - t0
+    grid.close()
+    pairs = P * (P - 1) // 2
+    return {"workload": "256^3 grid, 64 weld points = %d pair searches x %d generations, 24 ants, lazy evaporation; then the 64-seam order" % (pairs, gens),
+            "slots_by_rule": pb.plan.last_slots, "batches": -(-pairs // pb.plan.last_slots), "t_pairs_s": t_pairs, "t_solver_create_s": pb.plan.last_create_s,
+            "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "pair_generations_per_s": pairs * gens / t_pairs,
+            "all_reached": bool(np.isfinite(cost).all()), "tour_cost": float(tour["L"][0]), "tour_iterations": int(tour["iters"][0])}
 
 
 def pair_planning_extra(ctx, grid, free, n):
@@ -245,6 +327,7 @@ def main():
     solver.begin(params(K, wl["rng_seed"]), ids[0], ids[1], streams=[wl["stream"]])
     ctx.sync()
     setup_ms = (time.perf_counter() - t_setup) * 1e3
+    # (stamping a launch costs the stream ~8 us -- measured: every generation stamped = -4 % on `value` -- so only every n-th is)
     solver.profile(True, args.profile_every)
     # global-best exchange (C4): libweldacs.so's own RCCL communicator (wa_comm_*, csrc/host_comm.inc -- what a C++ host uses);
     # torch.distributed only ships the 128-byte id and provides the contract's barrier.  WA_BENCH_TORCH_ALLREDUCE=1 selects the
@@ -306,31 +389,36 @@ def main():
             assert np.array_equal(torch.stack(allh).min(0).values.cpu().numpy().view(np.uint32), glob.view(np.uint32)), "RCCL MIN != MIN of the gathered histories"
     best_all = wd.max_over_ranks(-float(cost), dev) * -1.0  # min over ranks
     if rank == 0:
-        # ---- fused launch (sweep + rank + mark share it): >= 32 per-dispatch samples whatever --steps is
+        # ---- the roofline kernel = the launch of the TIMED loop that carries the evaporation sweep (k_evap_rank_mark: 4096 sweep
+        # blocks + the rank / mark blocks), per-dispatch HIP events on the library's stream over the timed region
         fused = dict(prof["evaporate"])
-        if fused["launches"] < 32:   # continue the same search, untimed, every launch stamped
+        fused_where = "%d launches of the timed region" % fused["launches"]
+        if fused["launches"] < 32:   # a short timed region: the same search goes on, untimed, every launch stamped, until 32 samples exist
             solver.profile(True, 1)
-            solver.run(32)
+            solver.run(32 - int(fused["launches"]))
             more = solver.profile_read()["evaporate"]
-            fused = {"ms": more["ms"], "launches": more["launches"]}
+            fused = {"ms": fused["ms"] + more["ms"], "launches": fused["launches"] + more["launches"]}
+            fused_where += " + %d of the same search continued behind it (stamping every launch inside the timed region would cost it 4 %%)" % more["launches"]
         fused_ms = fused["ms"] / max(fused["launches"], 1)
-        # ---- the roofline kernel on its own, at the BASELINE size and past the Infinity Cache
+        # ---- beside it: the sweep kernel on its own, at the BASELINE size and past the Infinity Cache
         r128 = sweep_roofline(ctx, n)
         r256 = sweep_roofline(ctx, 256) if not args.no_roofline_256 else None
         alg_bytes = r128["algorithmic_bytes_per_launch"]  # 6 fp32 read + written per voxel
-        achieved = r128["achieved"]
+        achieved = alg_bytes / (fused_ms * 1e-3) / 1e9 if fused_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot host rocprofv3
-        # itself): only quoted when that file is about THIS kernel at THIS size
-        traffic, traffic_256, traffic_src = None, None, None
+        # itself): only quoted for the kernel and size they were measured on
+        traffic, traffic_alone, traffic_256, traffic_src = None, None, None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt["kernel"] == "k_evaporate":
-                g = pt["grids"]
-                if str(n) in g:
-                    traffic = float(g[str(n)]["fetch_bytes_corrected"] + g[str(n)]["write_bytes"])
-                if "256" in g and r256:
-                    traffic_256 = float(g["256"]["fetch_bytes_corrected"] + g["256"]["write_bytes"])
-                traffic_src = pt["source"]
+            g = pt["kernels"]["k_evaporate"]["grids"]
+            if str(n) in g:
+                traffic_alone = float(g[str(n)]["fetch_bytes_corrected"] + g[str(n)]["write_bytes"])
+            if "256" in g and r256:
+                traffic_256 = float(g["256"]["fetch_bytes_corrected"] + g["256"]["write_bytes"])
+            g = pt["kernels"].get("k_evap_rank_mark", {}).get("grids", {})
+            if str(n) in g:
+                traffic = float(g[str(n)]["fetch_bytes_corrected"] + g[str(n)]["write_bytes"])
+            traffic_src = pt["source"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -344,19 +432,17 @@ def main():
                        "global_best_allreduce": ("RCCL MIN over ranks per generation, chunks of %d, async, %s" % (
                            chunk, "torch.distributed" if use_torch_ar else "libweldacs wa_acs_allreduce_best (ncclAllReduce ncclMin on the communicator's stream)"))
                        if dist_on else "n/a (1 GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "k_evaporate (the evaporation sweep, launched alone %d times after the timed region; "
-                                                   "per-dispatch HIP events on the library's stream)" % r128["launches"],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": r128["avg_launch_ms"], "sampled_launches": r128["launches"],
-                         "note": "two 48 MiB buffers fit the 256 MiB Infinity Cache at this size; frac_256 is the past-the-cache figure",
-                         "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None, "traffic_256": traffic_256,
-                         "sweep_256": r256,
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_evap_rank_mark<false,6> -- the launch of the timed loop that carries the evaporation sweep (ACSRank_3D.hpp:268-272) "
+                                   "beside the rank / mark blocks; per-dispatch HIP events on the library's stream, " + fused_where,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": fused_ms, "sampled_launches": fused["launches"],
+                         "note": "at 128^3 both 48 MiB buffers sit in the 256 MiB Infinity Cache: frac is an on-die figure; sweep_alone.frac_256 is the HBM one",
+                         "sweep_alone": {"kernel": "k_evaporate, launched alone %d times after the timed region" % r128["launches"],
+                                         "frac_128": r128["achieved"] / HBM_PEAK_GBS, "avg_launch_ms_128": r128["avg_launch_ms"], "traffic_128": traffic_alone,
+                                         "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None, "traffic_256": traffic_256, "sweep_256": r256},
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
-            "fused_launch": {"kernel": "k_evap_rank_mark (sweep + rank + deposit marks of one generation in one launch)",
-                             "avg_launch_ms": fused_ms, "sampled_launches": fused["launches"],
-                             "sweep_share_GBps": alg_bytes / (fused_ms * 1e-3) / 1e9 if fused_ms > 0 else 0.0},
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
             "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
@@ -377,7 +463,10 @@ def main():
         if world == 1:
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
+            out["full_run"] = full_run_extra(solver, params, ids, wl, n)
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
+            solver.close()
+            out["c5_full"] = c5_full_extra(ctx)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

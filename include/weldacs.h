@@ -191,6 +191,9 @@ int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, 
 /* kernel timing with HIP events on the context stream.  Enable before wa_acs_run; afterwards
  * ms[i]/launches[i] hold the summed event time and launch count of kernel class i. */
 enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_COUNT = 4 };
+/* enable: 0 off; 1 every sample_every-th generation has all its launches stamped; 3 = the same, and the launch that carries the
+ * evaporation sweep is stamped in EVERY generation (per-dispatch start/stop events of hipExtLaunchKernelGGL: no extra stream
+ * operation, so the timed loop is not perturbed -- what bench.py's roofline figure uses) */
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
 /* diagnostic cycle counters of the walk's inner loop: all zero unless the library was built with

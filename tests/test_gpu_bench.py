@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "4", "--cpu-gens", "3"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -28,13 +28,22 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert rf["algorithmic_bytes_per_launch"] == 48.0 * 128 ** 3
-    # the roofline figure comes from the sweep kernel launched alone (>= 64 stamped launches whatever --steps is), at the
-    # BASELINE size and past the Infinity Cache; measured traffic (committed PMC passes) is within 2 % of the algorithmic bytes
-    assert rf["sampled_launches"] >= 64 and rf["kernel"].startswith("k_evaporate")
-    assert 0.3 < rf["frac_256"] < 1.0 and rf["sweep_256"]["algorithmic_bytes_per_launch"] == 48.0 * 256 ** 3
-    assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.02 and abs(rf["traffic_256"] / (48.0 * 256 ** 3) - 1.0) < 0.02
-    assert d["fused_launch"]["sampled_launches"] >= 32 and d["fused_launch"]["avg_launch_ms"] > rf["avg_launch_ms"] * 0.9
+    # the roofline figure is the launch of the TIMED loop that carries the sweep (k_evap_rank_mark), stamped per dispatch over
+    # the timed region; the sweep kernel launched alone (>= 64 stamped launches, at the BASELINE size and past the Infinity
+    # Cache) stands beside it; measured traffic (committed PMC passes) is within 2 % of the algorithmic bytes where it is quoted
+    assert rf["kernel"].startswith("k_evap_rank_mark") and rf["sampled_launches"] >= 32
+    sa = rf["sweep_alone"]
+    assert sa["kernel"].startswith("k_evaporate") and 0.3 < sa["frac_256"] < 1.0 and sa["frac_128"] >= rf["frac"] * 0.95
+    assert sa["sweep_256"]["algorithmic_bytes_per_launch"] == 48.0 * 256 ** 3
+    assert abs(sa["traffic_128"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.02 and abs(sa["traffic_256"] / (48.0 * 256 ** 3) - 1.0) < 0.02
+    assert rf["traffic"] is None or abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.05
+    ws = d["walk_step"]
+    assert ws["instructions_per_step"] > 40 and ws["isa_file"].endswith("walk_loop_isa.txt") and 0.3 < ws["frac_of_issue_floor"] < 1.0
+    fr, c5 = d["full_run"], d["c5_full"]
+    assert fr["generations"] == 500 and fr["best_cost"] == 378.0 and fr["generations_per_s"] > d["value"]
+    assert c5["all_reached"] is True and c5["slots_by_rule"] * c5["batches"] >= 2016 and c5["t_pairs_s"] < 10
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
-    assert d["cost_check"]["bit_equal_trace"] is True  # the GPU's best-cost history equals the CPU port's
+    cc = d["cost_check"]   # all 60 timed generations replayed by the CPU port: history and final best path equal
+    assert cc["bit_equal_trace"] is True and cc["generations"] == 60 and cc["best_path_equal"] is True
     assert abs(d["ms_per_step"] * d["value"] / 1e3 - 1.0) < 1e-6

@@ -791,11 +791,22 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         constexpr bool knob_never = false, knob_anywhere = false;
         int32_t hold = 1, backoff = 1;
 #endif
+#ifdef WA_ANT_TIME
+        unsigned long long dbg_hand = 0, dbg_gain = 0, dbg_t_hand = 0;
+        const int32_t dbg_prefix = st.len;
+#endif
         for (;;) {
             wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                              D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
+#ifdef WA_ANT_TIME
+            if (dbg_t_hand) { dbg_t_hand = 0; }
+#endif
             if (st.done || st.reason != 4) break;
+#ifdef WA_ANT_TIME
+            dbg_hand++;
+            const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+#endif
             int32_t gained = 0;
             const uint32_t mk = mark[st.cur];
             const int32_t ps = bpos[st.cur];                      // (fetched beside the stamp, meaningful only under it)
@@ -831,8 +842,20 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             }
             if (gained > 0) { backoff = 1; hold = 1; }
             else { hold = backoff; backoff = backoff < 32 ? backoff * 2 : 32; }   // the table does not apply here: walk on before asking again
+#ifdef WA_ANT_TIME
+            dbg_gain += (unsigned long long)gained;
+            dbg_t_hand = 1;
+            if (lane == 0 && D.dbg) atomicAdd(&D.dbg[13], (unsigned long long)__builtin_readcyclecounter() - dbg_t0);   // ticks between leaving the loop and re-entering it (re-entry prologue not included)
+#endif
             if (st.len >= fast_limit) break;
         }
+#ifdef WA_ANT_TIME
+        if (lane == 0 && D.dbg) {   // [12] the ant with the most hand-backs: (hand-backs, nodes gained on the replay track, general steps, replayed prefix); [14] += hand-backs, [15] += ants in this loop
+            atomicMax(&D.dbg[12], (dbg_hand << 48) | (dbg_gain << 32) | ((unsigned long long)(st.len - dbg_prefix - (int32_t)dbg_gain) << 16) | (unsigned long long)dbg_prefix);
+            atomicAdd(&D.dbg[14], dbg_hand);
+            atomicAdd(&D.dbg[15], 1ULL);
+        }
+#endif
         if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it
     } else if (st.len < fast_limit && use_asm) {
         WA_PHASE(8);
