@@ -232,6 +232,14 @@ __device__ __forceinline__ void tabu_insert(const WaTabu &t, int32_t key)
     t.tab[h] = key;
 }
 
+// lane `lane_uniform` of v := val_uniform (both wave-uniform).  The s_nop covers the wait states the assembler cannot see through the
+// inline statement (an SGPR written by a VALU instruction -- v_readlane -- read as data / lane select by the next VALU instruction)
+__device__ __forceinline__ int32_t wa_writelane(int32_t v, int32_t val_uniform, int32_t lane_uniform)
+{
+    asm volatile("s_mov_b32 m0, %2\n s_nop 3\n v_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val_uniform), "s"(lane_uniform) : "m0");   // (one SGPR + m0: the constant bus takes no two SGPRs)
+    return v;
+}
+
 // lane i <- lane i-1 (row_shr:1) / lane i <- lane i+1 (row_shl:1); lanes shifted in read 0
 __device__ __forceinline__ float dpp_from_below(float x)
 {
@@ -1987,6 +1995,105 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     }
     float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
     const int64_t last_rec = (D.d.n - 1) * 26;
+    if (MODE == 1 && R.alpha == 1 && len <= spill_at && len < (int32_t)D.path_cap && 104LL * D.d.n < (1LL << 31)) {
+        // ---- the general step while the tabu set lives in the LDS hash (DEV mode, alpha == 1, fields below 2 GB so that byte offsets fit
+        // 32 bits): the same arithmetic as the loop below, with what a LONE wavefront pays for taken out of the step (it issues one
+        // instruction per ~4 cycles whatever the type, see walk_loop_gfx950.hpp): the 64 draws of a block of steps are formed at once
+        // (lane i = step base + i) and picked with a readlane; offset, path word and step length of the pick come out of lane constants
+        // with one readlane each instead of the cube arithmetic; path words collect in a register and leave as one 256-byte store per
+        // 64 steps; the probe's terminating empty slot of the picked lane is the insertion slot (one ds_write, no second chain walk);
+        // the records of the NEXT voxel and its tabu probe are requested right behind the pick, before the bookkeeping, and the touch
+        // loads for the step after that follow them; addresses are 32-bit byte offsets from scalar bases.
+        const uint32_t dkw = (uint32_t)dk + ((uint32_t)k << WaNbT<26>::SHIFT);   // cur + this = path word of the move along edge k
+        const int typek = (dx != 0) + (dy != 0) + (dz != 0);
+        const float dlen = typek == 1 ? d1 : typek == 2 ? d2 : d3;                 // :369-385
+        const uint32_t hk = (uint32_t)dk * 2654435761u;                            // hash(cur + dk) = cur * K + dk * K
+        const char *pher_b = reinterpret_cast<const char *>(pher), *heur_b = reinterpret_cast<const char *>(heur);
+        const uint32_t lane_off = (uint32_t)k * 4u;                                // this lane's edge inside a 104-byte record
+        const int32_t last_vox = (int32_t)D.d.n - 1;
+        int32_t pbuf = 0;                                                          // lane i = path word (len & ~63) + i
+        if (r_node > 0) { if (lane < (len & 63)) pbuf = D.bestpath[(int64_t)slot * D.path_cap + (len & ~63) + lane]; }
+        else pbuf = start;                                                         // (lane 0 is the only one that counts: len == 1)
+        float ublock = (float)wa_ctr_draw(antkey, (step & ~63u) + (uint32_t)lane) / 2147483648.0f;   // (float)rand()/(float)RAND_MAX (:169)
+        // Vector memory returns in order and the compiler's waitcnt pass would wait for the youngest load it knows: the loop's six loads
+        // per step are therefore inline statements with an exact wait -- the two record loads (needed at the top of the next step) are
+        // issued FIRST, the four touch loads behind them land in registers nobody reads (v250..v253, never allocated otherwise: the
+        // kernel needs ~30) and stay in flight across the `s_waitcnt vmcnt(4)`.  (Loads the pass does not see only make its own waits
+        // stricter than it thinks, never weaker.)
+        float p = -0.f, h = 0.f;
+        {
+            const uint32_t off = (uint32_t)cur * 104u + lane_off;
+            asm volatile("global_load_dword %0, %2, %3\n global_load_dword %1, %2, %4\n s_waitcnt vmcnt(0)"
+                         : "=&v"(p), "=&v"(h) : "v"(off), "s"(pher_b), "s"(heur_b) : "memory");
+        }
+        // tabu probe of neighbour k (:145): ends on the key (visited) or on an empty slot (not visited; where the key would go)
+        uint32_t hs = ((uint32_t)cur * 2654435761u + hk) >> T.shift;
+        int32_t tv = tab[hs];
+        bool alive = true;
+        while (len <= spill_at && len < (int32_t)D.path_cap) {
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(p), "+v"(h));                 // this step's records; the touch loads stay in flight
+            const int32_t key = cur + dk;
+            while (tv != key && tv != WA_HASH_EMPTY) { hs = (hs + 1) & T.mask; tv = tab[hs]; }   // (rare: the slot held another key)
+            const bool adm = lane < 26 && (__float_as_uint(p) >> 31) == 0 && tv != key;   // sign bit: out of bounds or occupied (:148)
+            const float a = adm ? fabsf(p) * h : 0.f;                              // :154 (alpha == 1)
+            const unsigned long long mb = __ballot(adm);
+            if (mb == 0) { L = INFINITY; alive = false; break; }                   // :162-166
+            float t = 0.f + a, c = 0.f + a;
+#pragma unroll
+            for (int i = 0; i < 25; i++) {
+                t = dpp_wave_from_below(t) + a;
+                c = dpp_wave_from_above(c) + a;
+            }
+            const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 25));
+            float rnd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ublock), (int)(step & 63u)));
+            rnd *= total;                                                          // :170
+            const unsigned long long hit = __ballot(adm && c >= rnd);             // first hit in descending edge order (:178)
+            if (hit == 0) { L = INFINITY; alive = false; break; }                  // :191-192
+            const int pick = 63 - __clzll((long long)hit);
+            const int32_t word = (int32_t)((uint32_t)cur + (uint32_t)__builtin_amdgcn_readlane((int)dkw, pick));
+            const int32_t next = word & WaNbT<26>::IDM;
+            const int32_t slot_pick = __builtin_amdgcn_readlane((int)hs, pick);   // where the picked neighbour's probe ended: empty
+            // the NEXT step's records and tabu probe first: their latency runs under the bookkeeping below
+            {
+                const uint32_t off = (uint32_t)next * 104u + lane_off;
+                asm volatile("global_load_dword %0, %2, %3\n global_load_dword %1, %2, %4" : "=&v"(p), "=&v"(h) : "v"(off), "s"(pher_b), "s"(heur_b) : "memory");
+            }
+            if (lane == 0) tab[slot_pick] = next;                                  // addNextNode :75 (before the probe below: LDS is in order)
+            hs = ((uint32_t)next * 2654435761u + hk) >> T.shift;
+            tv = tab[hs];
+            {   // ... then the touches for the step after that (both ends of every neighbour's two records)
+                int32_t v2 = next + dk;
+                v2 = v2 < 0 ? 0 : v2 > last_vox ? last_vox : v2;
+                const uint32_t off = (uint32_t)v2 * 104u;
+                asm volatile("global_load_dword v250, %0, %1\n global_load_dword v251, %0, %1 offset:100\n"
+                             "global_load_dword v252, %0, %2\n global_load_dword v253, %0, %2 offset:100"
+                             : : "v"(off), "s"(pher_b), "s"(heur_b) : "memory", "v250", "v251", "v252", "v253");
+            }
+            pbuf = wa_writelane(pbuf, word, len & 63);                             // :76-77
+            len++;
+            if ((len & 63) == 0) path[len - 64 + lane] = pbuf;
+            L += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dlen), pick));   // :78
+            step++;
+            if ((step & 63u) == 0) ublock = (float)wa_ctr_draw(antkey, step + (uint32_t)lane) / 2147483648.0f;
+            cur = next;
+            if (next == end) { alive = false; break; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253");   // the last touches land before anything else runs
+        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;                    // the partial last block
+        if (!alive || len >= (int32_t)D.path_cap) {
+            if (alive) {   // the next step would not fit path[]
+                if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
+                L = INFINITY;
+            }
+            if (lane == 0) {
+                D.antL[(int64_t)slot * D.max_colony + ant] = L;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = len;
+            }
+            return;
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();   // the hash is nearly full: the loop below moves the set to the bitmap (it reads path[] back) and goes on
+    }
     for (;;) {
         if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
             __threadfence();

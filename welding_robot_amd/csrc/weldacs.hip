@@ -79,11 +79,6 @@ struct wa_acs {
     std::vector<float> heur_beta;       // ... and the last wa_acs_begin that used it (oldest goes first)
     std::vector<long long> heur_used;
     long long heur_batch;
-    // experiment: the sweep on a second stream beside the walk (WA_SWEEP_STREAM=1)
-    bool sweep_side;
-    int32_t sweep_side_blocks;
-    hipStream_t side;
-    hipEvent_t ev_sweep, ev_apply;
     // profiling
     bool prof, prof_sweep_all;   // prof_sweep_all: the sweep-carrying launch of EVERY generation carries its own start/stop events
     int32_t prof_every;
