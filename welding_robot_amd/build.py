@@ -24,7 +24,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm", "-Wno-pass-failed"]
 
 
 def hipcc():

@@ -2201,7 +2201,7 @@ __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash
     int32_t r[31];
     for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
     int32_t f = D.rng->f, b = D.rng->b;
-    const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
+    const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
         wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0);
     if (threadIdx.x == 0) {
