@@ -309,6 +309,7 @@
     WA_ASM_WARM1_##W                                                                                              \
     INFO2(X)                                                                                                      \
     WA_SPAN_3                                                                                                     \
+    "Lwa_masks_" X "%=:\n"                                        /* a collision comes back here: records, info and touch loads are done */ \
     WA_ASM_MASKS(X)                                                                                               \
     "v_cndmask_b32 v78, 0, v78, s[52:53]\n"                                                                       \
     WA_SPAN_4                                                                                                     \
@@ -345,7 +346,7 @@
     "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* arrived (:182): event */                     \
     WA_SPAN_10                                                                                                    \
     WA_ASM_STAMP(77)
-// some lane's probe hit another key: advance those lanes along their chains, then evaluate the step again
+// some lane's probe hit another key: advance those lanes along their chains, compare again and re-enter at the masks
 #define WA_ASM_COLL(X)                                                                                            \
     "Lwa_coll_" X "%=:\n"                                                                                         \
     WA_ASM_COUNT_COLL                                                                                             \
@@ -356,7 +357,10 @@
     "ds_read_b32 v75, v77\n"                                                                                      \
     "s_mov_b64 exec, s[58:59]\n"                                                                                  \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    "s_branch Lwa_redo_" X "%=\n"
+    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* the two probe compares again; sign mask and info of the first pass stand */ \
+    "v_cmp_ne_u32 s[48:49], -1, v75\n"                                                                            \
+    "s_nop 3\n"                                                                                                   \
+    "s_branch Lwa_masks_" X "%=\n"
 // no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
 // CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
 #define WA_ASM_RARE_BODY(CP, CH, IDX)                                                                             \
