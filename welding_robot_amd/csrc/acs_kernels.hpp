@@ -694,6 +694,9 @@ __device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
         for (int u = 0; u < 8; u++) tab4[i + u * 64] = e;
     }
     for (; i < n16; i += 64) tab4[i] = e;
+    // the entry behind the table is a sentinel: the hand-scheduled loop reads every probed slot together with its successor, and the
+    // successor of the LAST slot is this one -- neither empty nor any key, so that lane takes the slow path to slot 0
+    if (lane == 0) reinterpret_cast<int32_t *>(tab4)[1 << hash_log2] = WA_HASH_SENTINEL;
 }
 
 template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>

@@ -15,6 +15,7 @@
 #define WA_K_SHIFT 29
 #define WA_ID_MASK 0x1FFFFFFFu
 #define WA_HASH_EMPTY (-1)
+#define WA_HASH_SENTINEL (-2)   // the entry behind the table (see wa_tabu_clear): never empty, never a voxel id
 #define WA_MAX_TRACKED_ERR 1
 
 enum { WA_FLAG_PATH_OVERFLOW = 1, WA_FLAG_COLONY_OVERFLOW = 2, WA_FLAG_BITMAP_USED = 4 };

@@ -19,7 +19,8 @@
 //     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
 //     dummy slot), limits are checked per 64-step block instead of per step.
 // Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
-#define WA_WALK_LDS_EXTRA 4096   // bytes behind the tabu hash: 64 dummy slots + 7 x 64 lane constants (+ 6 x 64 diagnostic sums)
+#define WA_WALK_LDS_EXTRA 4160   // bytes behind the tabu hash: the sentinel slot (+ padding to 64 B), 64 dummy slots, 15 x 64 lane constants / diagnostic sums
+#define WA_WALK_LDS_PAD 16       // entries between the table and the dummy slots; entry 0 of them is the sentinel (never empty, never a key)
 #define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
 #define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
 // The records two hops away are touched with two 16-byte loads nobody waits for (W = SELF), or not at all (W = NONE):
@@ -279,7 +280,7 @@
     "v_add_u32 v77, s41, v67\n"                                                                                   \
     "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
     "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
-    "ds_read_b32 v75, v77\n"                                      /* next step's tabu probe */                    \
+    "ds_read2_b32 v[100:101], v77 offset1:1\n"                     /* next step's tabu probe: the slot and its successor (the chain's second slot) */ \
     "v_add_u32 v76, %[cur], v68\n"
 // the probe goes first: its LDS round trip (~50 cycles) then runs under the record loads' issue instead of in front of the next
 // step's head (measured, tools/walk_ab.py: -1 % on the step)
@@ -298,8 +299,8 @@
     WA_ASM_STAMP(73)                                                                                              \
     REJ(X)                                                        /* once per step: a re-evaluation (collision, block boundary) enters below */ \
     "Lwa_redo_" X "%=:\n"                                                                                         \
-    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* probed slot does not hold the neighbour */   \
-    "v_cmp_ne_u32 s[48:49], -1, v75\n"                            /* ... and is not empty: chain goes on */       \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                               /* probed slot does not hold the neighbour */   \
+    "v_cmp_ne_u32 s[48:49], -1, v100\n"                           /* ... and is not empty: chain goes on */       \
     VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
     WA_SPAN_2                                                                                                     \
     WA_ASM_STAMP(74)                                                                                              \
@@ -352,15 +353,32 @@
     WA_ASM_COUNT_COLL                                                                                             \
     "s_mov_b64 s[58:59], exec\n"                                                                                  \
     "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "v_mov_b32 v100, v101\n"                                      /* the chain's second slot came with the probe: no LDS round trip */ \
     "v_add_u32 v77, 4, v77\n"                                                                                     \
-    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
-    "ds_read_b32 v75, v77\n"                                                                                      \
+    "v_and_b32 v77, %[hm4], v77\n"                                /* (a probe of the table's LAST slot read the sentinel as its successor: it compares */ \
+    "s_mov_b64 exec, s[58:59]\n"                                  /*  as another key and the loop below reads the real successor, slot 0) */ \
+    "Lwa_coll_cmp_" X "%=:\n"                                                                                     \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                               /* the two probe compares again; sign mask and info of the first pass stand */ \
+    "v_cmp_ne_u32 s[48:49], -1, v100\n"                                                                           \
+    "s_nop 3\n"                                                                                                   \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc0 Lwa_masks_" X "%=\n"                                                                          \
+    "s_mov_b64 exec, s[48:49]\n"                                  /* still another key: read the slot the chain stands on (after a fast pass the one */ \
+    "ds_read_b32 v100, v77\n"                                     /* just compared, else the next), and advance behind it for the pass after */ \
     "s_mov_b64 exec, s[58:59]\n"                                                                                  \
     "s_waitcnt lgkmcnt(0)\n"                                                                                      \
-    "v_cmp_ne_u32 vcc, v75, v76\n"                                /* the two probe compares again; sign mask and info of the first pass stand */ \
-    "v_cmp_ne_u32 s[48:49], -1, v75\n"                                                                            \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                                                                               \
+    "v_cmp_ne_u32 s[48:49], -1, v100\n"                                                                           \
     "s_nop 3\n"                                                                                                   \
-    "s_branch Lwa_masks_" X "%=\n"
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc0 Lwa_masks_" X "%=\n"                                                                          \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "v_add_u32 v77, 4, v77\n"                                                                                     \
+    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
+    "ds_read_b32 v100, v77\n"                                                                                     \
+    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "s_branch Lwa_coll_cmp_" X "%=\n"
 // no candidate: a pending event (block complete / arrived: active mask zeroed by the previous step) or a dead end.
 // CP/CH are the records of `cur`: they go back to the caller, who re-enters after a block boundary.
 #define WA_ASM_RARE_BODY(CP, CH, IDX)                                                                             \
@@ -390,7 +408,7 @@
     "v_add_u32 v77, s41, v67\n"                                                                                   \
     "v_lshrrev_b32 v77, %[hs], v77\n"                                                                             \
     "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
-    "ds_read_b32 v75, v77\n"                                                                                      \
+    "ds_read2_b32 v[100:101], v77 offset1:1\n"                                                                    \
     "v_add_u32 v76, %[cur], v68\n"                                                                                \
     "s_mul_i32 s40, %[cur], 24\n"                /* records of cur's six neighbours: what the first step's tail would have requested */ \
     "v_add_u32 v82, s40, v65\n"                                                                                   \
@@ -466,7 +484,7 @@
     WA_ASM_STAMPS_DUMP                                                                                            \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
 #define WA_ASM_CLOBBERS                                                                                           \
-    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82",  \
+    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v100", "v101", "v76", "v77", "v78", "v79", "v80", "v81", "v82",  \
         "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44",     \
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
@@ -579,14 +597,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
     const char *stamp_b = LAZY ? reinterpret_cast<const char *>(stamp) - stamp_guard_bytes : nullptr;
     {   // lane constants (columns of 64 dwords behind the dummy slots)
-        int32_t *lc = tab + table + 64;
+        int32_t *lc = tab + table + WA_WALK_LDS_PAD + 64;
         lc[0 * 64 + lane] = lane;
         lc[1 * 64 + lane] = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
         lc[2 * 64 + lane] = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
         lc[3 * 64 + lane] = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
         lc[4 * 64 + lane] = dk;
         lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
-        lc[6 * 64 + lane] = (table + lane) * 4;                                      // this lane's dummy slot
+        lc[6 * 64 + lane] = (table + WA_WALK_LDS_PAD + lane) * 4;                    // this lane's dummy slot
         if (LAZY) {
             lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
         }
@@ -595,7 +613,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
                                  : lane == 3 ? (int32_t)ver : hold_off;
     }
-    const int32_t lcaddr = (table + 64 + lane) * 4;
+    const int32_t lcaddr = (table + WA_WALK_LDS_PAD + 64 + lane) * 4;
     int32_t cur = st.cur, len = st.len, g8 = 0;
     int32_t pbuf = st.cur;
     if (REJOIN && st.pbuf_valid) pbuf = st.pbuf;
@@ -626,7 +644,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {
-            const int32_t *lcs = tab + table + 64;
+            const int32_t *lcs = tab + table + WA_WALK_LDS_PAD + 64;
             for (int i = 0; i < 6; i++) atomicAdd(&dbg[i], (unsigned long long)(uint32_t)lcs[(7 + i) * 64]);
         }
 #endif
