@@ -718,6 +718,14 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     const int32_t *prefix_words = nullptr;
     if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
+        // the first 512 words of the best path are requested BEFORE the replay decides how many of them the ant walks: their round trip
+        // runs beside the table rows' (once converged every ant copies all of them)
+        int32_t w0[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int32_t q = u * 64 + lane;
+            w0[u] = q < rlen ? bpath[q] : 0;
+        }
         const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
 #ifdef WA_STAMPS
         if (lane == 0 && D.dbg) {   // diagnostic: how far do ants follow the best path?  [10] += nodes replayed, [11] += ants,
@@ -729,7 +737,12 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         st.len = node + 1;
         // the walked prefix IS the best path's.  512 words per round: eight independent loads per lane, then eight stores
         // (a load-store pair per round would put one memory round trip per 64 words on every converged walk)
-        for (int32_t q0 = 0; q0 < st.len; q0 += 512) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int32_t q = u * 64 + lane;
+            if (q < st.len) path[q] = w0[u];
+        }
+        for (int32_t q0 = 512; q0 < st.len; q0 += 512) {
             int32_t w[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
