@@ -1436,22 +1436,33 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const float *antL = D.antL + (int64_t)slot * D.max_colony;
     const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
     __shared__ unsigned long long s_keys[WA_RANK_LDS];
-    __shared__ int32_t s_perm[WA_RANK_LDS];
+    __shared__ int32_t s_perm[WA_RANK_LDS], s_len[WA_RANK_LDS];
     __shared__ int32_t s_ndep, s_fin;
     __shared__ unsigned long long s_steps;
     if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
+    // This block is a chain of dependent global loads beside a sweep that saturates the memory system (every level costs 2-3 us there):
+    // the ants' results are requested for ALL max_colony ants before the control block says how many there are (inside the allocation;
+    // entries beyond the colony are never looked at), and every ant's length goes to LDS with its key, so that the ranked ant's length is
+    // an LDS read: control block + results -> path words -> marks, three levels instead of five.
+    const int32_t cmax = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
+    for (int32_t a = tid; a < cmax; a += blockDim.x) {
+        const float La = antL[a];
+        const int32_t na = antLen[a];
+        s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
+        s_len[a] = na;
+    }
     if (colony > D.max_colony || colony > WA_RANK_LDS) {
         if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
         return;
     }
+    __syncthreads();
     int32_t myfin = 0;
     unsigned long long mysteps = 0;
-    for (int32_t a = tid; a < colony; a += blockDim.x) {
-        const float La = antL[a];
-        s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
-        if (mb == 0) { myfin += (La != INFINITY) ? 1 : 0; mysteps += (unsigned long long)(antLen[a] - 1); }
-    }
-    __syncthreads();
+    if (mb == 0)
+        for (int32_t a = tid; a < colony; a += blockDim.x) {
+            myfin += (__uint_as_float((uint32_t)(s_keys[a] >> 32)) != INFINITY) ? 1 : 0;
+            mysteps += (unsigned long long)(s_len[a] - 1);
+        }
     for (int32_t a = tid; a < colony; a += blockDim.x) {  // ascending (L, ant) by counting (:273-275, DEV tie rule)
         const unsigned long long ka = s_keys[a];
         int32_t r = 0;
@@ -1476,13 +1487,13 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     if (mb == 0) {  // ---- publish: iteration best -> global best (:263-264), trace, next parameters (:247-249)
         float iterL = INFINITY;
         int32_t iterAnt = -1;
-        if (colony > 0) { iterAnt = s_perm[0]; iterL = antL[iterAnt]; }  // rank 1 = first ant with the minimal L
+        if (colony > 0) { iterAnt = s_perm[0]; iterL = __uint_as_float((uint32_t)(s_keys[iterAnt] >> 32)); }  // rank 1 = first ant with the minimal L
         float bestL = ctl->bestL;
         uint32_t ver = ctl->best_ver;
         int32_t blen = ctl->best_len;
         bool changed = false;
         if (iterAnt >= 0 && iterL < bestL) {
-            blen = antLen[iterAnt];
+            blen = s_len[iterAnt];
             const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
             int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
             uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
@@ -1525,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
     if (o > n_dep) return;
     const int32_t a = s_perm[o - 1];
-    const int32_t len = antLen[a];
+    const int32_t len = s_len[a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
     const WaMaskRef mask = wa_mask_of(D, slot);
     float *ph = dst_base + (int64_t)slot * D.pher_stride;
