@@ -338,8 +338,17 @@ def main():
     if dist_on and not use_torch_ar:
         uid = torch.from_numpy(api.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
         dist.broadcast(uid, src=0)
-        comm = api.Comm(ctx, rank, world, uid.cpu().numpy())
-        comm.barrier()
+        try:
+            comm = api.Comm(ctx, rank, world, uid.cpu().numpy())
+            comm.barrier()
+            ok = 1.0
+        except api.WeldacsError as e:   # (never seen; every rank must take the same path, so the ranks agree on it below)
+            print("[bench] rank %d: wa_comm_create failed (%s)" % (rank, e), file=sys.stderr)
+            comm, ok = None, 0.0
+        if wd.max_over_ranks(-ok, dev) != -1.0:   # some rank failed: everybody exchanges through torch.distributed instead
+            if comm is not None:
+                comm.close()
+            comm, use_torch_ar = None, True
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev) if use_torch_ar else None
     gbuf = [torch.empty(chunk, dtype=torch.float32, device=dev) for _ in range((K + chunk - 1) // chunk)] if use_torch_ar else []
     works = []
