@@ -65,6 +65,41 @@ def test_nb26_tabu_spill_to_bitmap(ctx):
         del os.environ["WA_HASH_LOG2"]
 
 
+def test_nb26_exact_path_capacity_and_every_path_word(ctx):
+    """The lone-wavefront general step of the 26-neighbour walk buffers its path words in a register (one store per 64 steps) and
+    leaves capacity / spill decisions to the generic loop: a walk that needs exactly path_capacity nodes fits, one node less is
+    WA_ERR_CAPACITY; and every ant's every path word equals the oracle's on walks that cross several 64-word blocks."""
+    line = O.Grid(np.arange(5, dtype=np.float32), np.zeros(1, np.float32), np.zeros(1, np.float32), np.ones(5, np.uint8), 1.0, 0)
+    dg = api.Grid.from_occupancy(ctx, line.free, line.cx, line.cy, line.cz, 1.0, 0)
+    p = api.default_params(max_iteration=3, predict=10.0, fixed_colony=4, rng_mode=api.RNG_DEV, seed=1)
+    s = api.AcsSolver(ctx, dg, 1, 4, path_capacity=5, neighbourhood=26)
+    s.solve(p, 0, 4)
+    cost, path, _ = s.result()
+    assert cost == 4.0 and path.tolist() == [0, 1, 2, 3, 4]
+    s.close()
+    s = api.AcsSolver(ctx, dg, 1, 4, path_capacity=4, neighbourhood=26)
+    with pytest.raises(api.WeldacsError) as e:
+        s.solve(p, 0, 4)
+    assert e.value.code == 7
+    s.close()
+    og = O.synth_grid(40, seed=77, occ_prob=0.12)
+    free = np.nonzero(og.free)[0]
+    sid, eid = int(free[0]), int(free[-1])
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    for gens in (1, 6):
+        s = api.AcsSolver(ctx, dg, 1, 48, neighbourhood=26)
+        p = api.default_params(max_iteration=gens, predict=120.0, fixed_colony=48, rng_mode=api.RNG_DEV, seed=5)
+        s.solve(p, sid, eid, streams=[3])
+        a = O.Acs(og, nb=26)
+        a.solve(sid, eid, gens, 120.0, fixed_colony=48, mode=O.DEV, seed=5, stream=3)
+        L, lens = s.ants()
+        olens, oL = a.last_ants()
+        assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL)) and lens.max() > 130
+        for i, op in enumerate(a.last_paths()):
+            assert np.array_equal(s.ant_path(i), op), (gens, i)
+        s.close()
+
+
 def test_nb26_batch_and_reset(ctx):
     og = ogrid("cubic.stl", "0.0219", 8)
     dg = dgrid_from(ctx, og)

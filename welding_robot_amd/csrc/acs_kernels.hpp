@@ -2107,11 +2107,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253");   // the last touches land before anything else runs
         if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;                    // the partial last block
-        if (!alive || len >= (int32_t)D.path_cap) {
-            if (alive) {   // the next step would not fit path[]
-                if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
-                L = INFINITY;
-            }
+        if (!alive) {
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = len;
@@ -2119,8 +2115,8 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             return;
         }
         __threadfence_block();
-        __builtin_amdgcn_wave_barrier();   // the hash is nearly full: the loop below moves the set to the bitmap (it reads path[] back) and goes on
-    }
+        __builtin_amdgcn_wave_barrier();   // the hash is nearly full (the loop below moves the set to the bitmap: it reads path[] back) or path[]
+    }                                      // is: the generic loop goes on from here and decides exactly as it always did
     for (;;) {
         if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
             __threadfence();
