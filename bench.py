@@ -24,7 +24,8 @@ start/stop) over the timed region; `achieved` = 48 N^3 / that average, `frac` ag
 both 48 MiB buffers sit in the 256 MiB Infinity Cache, so beside it `sweep_alone` reports the sweep kernel itself
 (`k_evaporate`, 64 stamped launches after the timed region) at 128^3 and at 256^3 (805 MB per launch: past the cache).
 Extras after the timed region, outside `value`: `full_run` (the same search over BASELINE config 3's stated 500
-generations), `c5_full` (BASELINE config 5 at full size on this GPU), `walk_step` (time per general step of the walk
+generations), `multi_start` (eight independent searches advancing together on this GPU: config 4's
+workload, with an HBM-resident sweep), `c5_full` (BASELINE config 5 at full size on this GPU), `walk_step` (time per general step of the walk
 against the issue floor of its assembled loop), `c5_pair_planning` (dense vs lazy evaporation, must agree).
 """
 import argparse
@@ -205,6 +206,36 @@ def full_run_extra(solver, params, ids, wl, n, gens=500):
             "generation_of_last_improvement": int((tr["bestL"] != tr["bestL"][-1]).sum()),
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()},
             "in_loop_frac": 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None}
+
+
+def multi_start_extra(ctx, grid, params, ids, n, ants, problems=8, gens=100):
+    """BASELINE config 4's workload on ONE GPU: `problems` independent searches of the same grid (different DEV streams: a multi-start
+    batch) advance together, one launch per kernel and generation for all of them.  A lone search leaves the chip almost empty (256
+    wavefronts); eight fill 2 048 wave slots for the same walk latency, and their sweep streams 8 x 100 MB per launch -- past the 256 MiB
+    Infinity Cache, so `in_loop_frac` here is an HBM figure.  Outside `value`."""
+    import numpy as np
+    from welding_robot_amd import api
+    s = api.AcsSolver(ctx, grid, n_slots=problems, max_colony=ants)
+    p = params(gens, 4242)
+    streams = list(range(100, 100 + problems))
+    s.init_pheromone(1.0)
+    s.begin(p, [ids[0]] * problems, [ids[1]] * problems, streams=streams)
+    s.run(5)                                                      # warm-up generations of the same searches
+    s.sync()
+    s.profile(True, 10)
+    t0 = time.perf_counter()
+    s.run(gens - 5)
+    s.sync()
+    dt = time.perf_counter() - t0
+    pr = s.profile_read()
+    costs, _ = s.results(problems)
+    fused_ms = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1)
+    s.close()
+    return {"workload": "%d independent %d^3 / %d-ant searches on one GPU, generations 5..%d of each" % (problems, n, ants, gens - 1),
+            "problem_generations_per_s": problems * (gens - 5) / dt, "ms_per_generation_of_all": dt * 1e3 / (gens - 5),
+            "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()},
+            "in_loop_frac": problems * 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None,
+            "bytes_per_launch": problems * 48.0 * n ** 3, "best_costs": [float(c) for c in costs]}
 
 
 def c5_full_extra(ctx):
@@ -473,6 +504,7 @@ def main():
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
             out["full_run"] = full_run_extra(solver, params, ids, wl, n)
+            out["multi_start"] = multi_start_extra(ctx, grid, params, ids, n, args.ants)
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
             solver.close()
             out["c5_full"] = c5_full_extra(ctx)
