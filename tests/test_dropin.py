@@ -147,3 +147,39 @@ def test_pair_loop_sharded_over_contexts_is_shard_invariant():
     longest = max(r[5] for r in shards[("0,0,0,0,0,0,0,0", 0)])      # eight shards, ten searches: the heaviest shard holds 1-2 searches
     assert max(w) - min(w) <= longest
     assert len(shards[("0,0,0,0,0,0,0,0", 0)]) == 8
+
+
+@pytest.mark.gpu
+def test_pair_loop_deals_whole_end_point_groups_when_there_are_enough():
+    """Ten weld points = 45 pair searches, 9 end-point groups: with two contexts (9 >= 4 x 2) the C++ pair loop deals WHOLE groups
+    longest-first (every end point lives on one shard), with one context nothing is dealt; costs and paths are the same bytes."""
+    import oracle_lib as O
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
+                        os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
+    tris = O.stl_parse(open(os.path.join(G, "cubic.stl"), "rb").read())
+    og = O.grid_from_mesh(tris, np.float32("0.0219"), 8)
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12), (4, 4, 20), (20, 27, 4), (12, 29, 12), (2, 15, 12), (22, 15, 12)]
+    pts = "/tmp/weldacs_ten_points_%d.in" % os.getpid()
+    with open(pts, "w") as f:
+        f.write("%d\n" % len(nodes))
+        for z, y, x in nodes:
+            assert og.free[(z * og.ny + y) * og.nx + x]
+            f.write("%f %f %f\n" % tuple(og.node_pt(z, y, x)))
+    outs, shards = {}, {}
+    for devs in ("0", "0,0"):
+        out = "/tmp/weldacs_groups_%s.txt" % devs.replace(",", "_")
+        rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", pts, "0.5", "99", devs, out, "0"], capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
+        outs[devs] = open(out, "rb").read()
+        shards[devs] = [[int(v) for v in l.split()[1:]] for l in open(out + ".shards")]
+        lines = [l for l in rr.stdout.splitlines() if l.startswith("[ACS 3D] shard")]
+        assert len(lines) == len(devs.split(","))
+    assert outs["0"].count(b"pair ") == 45 and outs["0"] == outs["0,0"]
+    two = shards["0,0"]
+    assert sum(r[2] for r in two) == 45 and all(r[2] > 0 for r in two)
+    w = [r[5] for r in two]
+    assert abs(w[0] - w[1]) <= 0.25 * max(w)      # whole groups of 1..9 searches: balanced to the size of a group
