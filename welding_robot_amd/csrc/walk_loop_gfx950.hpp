@@ -493,7 +493,30 @@
 // collision and rare-event stubs).  Measured at C3, walk launches of generations 0-10, loop top at 64 B + 4k bytes: k = 0 190.0 us,
 // 2 188.7, 4 187.1, 6 187.5, 8 190.4, 10 189.7, 12 186.7, 14 187.1 -- so the dense loops are pinned at k = 12 instead of left to
 // whatever the code in front of them happens to add up to.
-#define WA_ASM_LOOP_ALIGN ".p2align 6\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"
+// (round 3, after the loop changed -- probe first, ds_read2, collision re-entry label: k = 0..15 measured again with tools/walk_ab.py, 159.1-163.2 ns
+// per step of the longest walk; 5, 12 and 13 are the best within noise, 12 stays)
+#ifndef WA_ALIGN_PAD
+#define WA_ALIGN_PAD 12
+#endif
+#define WA_ASM_NOPS_0 ""
+#define WA_ASM_NOPS_1 " s_nop 0\n"
+#define WA_ASM_NOPS_2 WA_ASM_NOPS_1 WA_ASM_NOPS_1
+#define WA_ASM_NOPS_3 WA_ASM_NOPS_2 WA_ASM_NOPS_1
+#define WA_ASM_NOPS_4 WA_ASM_NOPS_2 WA_ASM_NOPS_2
+#define WA_ASM_NOPS_5 WA_ASM_NOPS_4 WA_ASM_NOPS_1
+#define WA_ASM_NOPS_6 WA_ASM_NOPS_4 WA_ASM_NOPS_2
+#define WA_ASM_NOPS_7 WA_ASM_NOPS_4 WA_ASM_NOPS_3
+#define WA_ASM_NOPS_8 WA_ASM_NOPS_4 WA_ASM_NOPS_4
+#define WA_ASM_NOPS_9 WA_ASM_NOPS_8 WA_ASM_NOPS_1
+#define WA_ASM_NOPS_10 WA_ASM_NOPS_8 WA_ASM_NOPS_2
+#define WA_ASM_NOPS_11 WA_ASM_NOPS_8 WA_ASM_NOPS_3
+#define WA_ASM_NOPS_12 WA_ASM_NOPS_8 WA_ASM_NOPS_4
+#define WA_ASM_NOPS_13 WA_ASM_NOPS_12 WA_ASM_NOPS_1
+#define WA_ASM_NOPS_14 WA_ASM_NOPS_12 WA_ASM_NOPS_2
+#define WA_ASM_NOPS_15 WA_ASM_NOPS_12 WA_ASM_NOPS_3
+#define WA_ASM_CAT_(a, b) a##b
+#define WA_ASM_CAT(a, b) WA_ASM_CAT_(a, b)
+#define WA_ASM_LOOP_ALIGN ".p2align 6\n" WA_ASM_CAT(WA_ASM_NOPS_, WA_ALIGN_PAD)
 #define WA_ASM_REJ_INIT "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n"
 #define WA_ASM_REJ_EXITS WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
 // the two dense loops as statements (W = SELF | NONE: the touch loads, see above)
