@@ -69,3 +69,41 @@ def test_in_place_compile_would_keep_the_reference_headers():
     got = resolved(r.stderr)
     for h in FIVE:
         assert got[h] == {os.path.realpath(REF + "/core")}, (h, got[h])
+
+
+def test_cmake_fragment_builds_the_reference_application_on_the_c_abi():
+    """INTEGRATION.md recipe A.1 run literally: a COPY of the reference tree (made at test time in a temp directory, never in the
+    repo), the two lines `file(GLOB USER_SOURCE ...)` / `add_executable(...)` of its CMakeLists.txt replaced by
+    `set(WELDACS ...)` + `include(weldacs_dropin.cmake)`, then cmake configure + build.  The resulting `welding_robot`
+    executable -- the reference's whole application shell: menu, simulator client, plotting -- links libweldacs.so and
+    its planning calls are the wa_* entry points."""
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    from welding_robot_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    tmp = tempfile.mkdtemp(prefix="weldacs_cmake_")
+    try:
+        src, bld = os.path.join(tmp, "src"), os.path.join(tmp, "build")
+        shutil.copytree(REF, src)
+        cml = os.path.join(src, "CMakeLists.txt")
+        text = open(cml).read()
+        old = 'file(GLOB USER_SOURCE "*.cpp")\nadd_executable(${PROJECT_NAME} ${USER_SOURCE})\n'
+        assert old in text
+        open(cml, "w").write(text.replace(old, "set(WELDACS %s)\ninclude(${WELDACS}/welding_robot_amd/cmake/weldacs_dropin.cmake)\n" % ROOT))
+        os.makedirs(bld)
+        r = subprocess.run(["cmake", src, "-DCMAKE_BUILD_TYPE=Release"], cwd=bld, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        r = subprocess.run(["cmake", "--build", ".", "-j4"], cwd=bld, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        exe = os.path.join(src, "build", "bin", "welding_robot")   # EXECUTABLE_OUTPUT_PATH of the reference's CMakeLists.txt
+        assert os.path.exists(exe)
+        assert "libweldacs.so" in subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        und = subprocess.run(["nm", "-u", "-C", exe], capture_output=True, text=True).stdout
+        for sym in ("wa_ctx_create", "wa_stl_read_file", "wa_grid_from_mesh", "wa_acs_solve", "wa_gtsp_solve", "wa_bspline_eval"):
+            assert sym in und, sym
+        # the shadow copy is what was compiled, the original main.cpp is untouched
+        assert os.path.exists(os.path.join(bld, "weldacs_shadow", "main.cpp"))
+        assert open(os.path.join(src, "main.cpp"), "rb").read() == open(os.path.join(REF, "main.cpp"), "rb").read()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
