@@ -20,7 +20,8 @@ kind "reference") or the C oracle (kind "port") timed on this host on a bounded 
 roofline: the launch of the timed loop that carries the evaporation sweep (ACSRank_3D.hpp:268-272: 48 B of
 algorithmic traffic per voxel) is `k_evap_rank_mark` -- 4096 sweep blocks + the latency-bound rank / mark blocks of the
 same generation.  Its launches are stamped per dispatch with HIP events on the library's own stream (hipExtLaunchKernelGGL
-start/stop) over the timed region; `achieved` = 48 N^3 / that average, `frac` against the 8 TB/s HBM3E peak.  At 128^3
+start/stop) over the timed region; `achieved` = 48 N^3 / that average, `frac` against the 8 TB/s HBM3E peak; `traffic` = HBM bytes per
+launch from two rocprofv3 PMC child passes of this very run (FETCH_SIZE / WRITE_SIZE; the committed passes when that is not possible).  At 128^3
 both 48 MiB buffers sit in the 256 MiB Infinity Cache, so beside it `sweep_alone` reports the sweep kernel itself
 (`k_evaporate`, 64 stamped launches after the timed region) at 128^3 and at 256^3 (805 MB per launch: past the cache).
 Extras after the timed region, outside `value`: `full_run` (the same search over BASELINE config 3's stated 500
@@ -206,6 +207,50 @@ def full_run_extra(solver, params, ids, wl, n, gens=500):
             "generation_of_last_improvement": int((tr["bestL"] != tr["bestL"][-1]).sum()),
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()},
             "in_loop_frac": 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None}
+
+
+def live_traffic(n, ants, timeout_s=150):
+    """HBM bytes per launch of the in-loop sweep launch, measured in THIS run: two child passes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as the guide's HBM section prescribes; 30 generations each),
+    summed per kernel, FETCH_SIZE doubled (gfx950 tallies the 128-B requests of a 16-B/lane streaming read at 64 B).  Returns
+    (bytes per launch, dispatches, source string) or None when rocprofv3 is missing, this process itself runs under a profiler, or a
+    pass fails -- the caller then quotes the committed passes (profiles/pmc_traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if os.environ.get("WA_BENCH_NO_LIVE_PMC") == "1" or shutil.which("rocprofv3") is None:
+        return None
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")):
+        return None   # never nest profilers
+    tmp = tempfile.mkdtemp(prefix="weld_pmc_")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "30", "--warmup", "2", "--no-cpu", "--no-extras", "--no-roofline-256", "--grid", str(n), "--ants", str(ants)]
+            env = dict(os.environ, WA_BENCH_NO_LIVE_PMC="1", TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and row["Kernel_Name"].startswith("void k_evap_rank_mark<false, 6>"):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            got[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))   # the counters are in KB
+        return (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0], got["FETCH_SIZE"][1],
+                "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run (30 generations each, %d dispatches), FETCH_SIZE doubled "
+                "per MI355X_MICROARCH.md (an over-count for the small reads of the rank / mark blocks: upper bound)" % got["FETCH_SIZE"][1])
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def multi_start_extra(ctx, grid, params, ids, n, ants, problems=8, gens=100):
@@ -458,9 +503,13 @@ def main():
             g = pt["kernels"].get("k_evap_rank_mark", {}).get("grids", {})
             if str(n) in g:
                 traffic = float(g[str(n)]["fetch_bytes_corrected"] + g[str(n)]["write_bytes"])
-            traffic_src = pt["source"]
+            traffic_src = "committed: " + pt["source"]
         except (OSError, KeyError, ValueError):
             pass
+        if world == 1 and not args.no_extras:   # measured in this run when rocprofv3 can wrap a child pass
+            lt = live_traffic(n, args.ants)
+            if lt is not None:
+                traffic, traffic_src = lt[0], lt[2] + "; sweep_alone.traffic_*: " + (traffic_src or "n/a")
         out = {
             "metric": "acs_generations_per_sec", "value": wd.aggregate_rate(total_gens, elapsed), "unit": "generations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,

@@ -36,7 +36,7 @@ def test_bench_json_contract():
     assert sa["kernel"].startswith("k_evaporate") and 0.3 < sa["frac_256"] < 1.0 and sa["frac_128"] >= rf["frac"] * 0.95
     assert sa["sweep_256"]["algorithmic_bytes_per_launch"] == 48.0 * 256 ** 3
     assert abs(sa["traffic_128"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.02 and abs(sa["traffic_256"] / (48.0 * 256 ** 3) - 1.0) < 0.02
-    assert rf["traffic"] is None or abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.05
+    assert abs(rf["traffic"] / rf["algorithmic_bytes_per_launch"] - 1.0) < 0.05 and rf["traffic_source"].startswith(("live:", "committed:"))
     ws = d["walk_step"]
     assert ws["instructions_per_step"] > 40 and ws["isa_file"].endswith("walk_loop_isa.txt") and 0.3 < ws["frac_of_issue_floor"] < 1.0
     ms = d["multi_start"]   # eight searches together on one GPU: more problem-generations/s than one alone, an HBM-resident sweep, all converge
