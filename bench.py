@@ -257,30 +257,40 @@ def multi_start_extra(ctx, grid, params, ids, n, ants, problems=8, gens=100):
     """BASELINE config 4's workload on ONE GPU: `problems` independent searches of the same grid (different DEV streams: a multi-start
     batch) advance together, one launch per kernel and generation for all of them.  A lone search leaves the chip almost empty (256
     wavefronts); eight fill 2 048 wave slots for the same walk latency, and their sweep streams 8 x 100 MB per launch -- past the 256 MiB
-    Infinity Cache, so `in_loop_frac` here is an HBM figure.  Outside `value`."""
+    Infinity Cache, so `in_loop_frac` here is an HBM figure.  The same batch with lazy evaporation (wa_acs_create_lazy: never-deposited
+    voxels are not swept) stands beside it and must give the same histories.  Outside `value`."""
     import numpy as np
     from welding_robot_amd import api
-    s = api.AcsSolver(ctx, grid, n_slots=problems, max_colony=ants)
-    p = params(gens, 4242)
-    streams = list(range(100, 100 + problems))
-    s.init_pheromone(1.0)
-    s.begin(p, [ids[0]] * problems, [ids[1]] * problems, streams=streams)
-    s.run(5)                                                      # warm-up generations of the same searches
-    s.sync()
-    s.profile(True, 10)
-    t0 = time.perf_counter()
-    s.run(gens - 5)
-    s.sync()
-    dt = time.perf_counter() - t0
-    pr = s.profile_read()
-    costs, _ = s.results(problems)
-    fused_ms = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1)
-    s.close()
-    return {"workload": "%d independent %d^3 / %d-ant searches on one GPU, generations 5..%d of each" % (problems, n, ants, gens - 1),
-            "problem_generations_per_s": problems * (gens - 5) / dt, "ms_per_generation_of_all": dt * 1e3 / (gens - 5),
-            "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()},
-            "in_loop_frac": problems * 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None,
-            "bytes_per_launch": problems * 48.0 * n ** 3, "best_costs": [float(c) for c in costs]}
+    out = {"workload": "%d independent %d^3 / %d-ant searches on one GPU, generations 5..%d of each" % (problems, n, ants, gens - 1)}
+    hist = {}
+    for lazy in (False, True):
+        s = api.AcsSolver(ctx, grid, n_slots=problems, max_colony=ants, lazy=lazy)
+        p = params(gens, 4242)
+        streams = list(range(100, 100 + problems))
+        s.init_pheromone(1.0)
+        s.begin(p, [ids[0]] * problems, [ids[1]] * problems, streams=streams)
+        s.run(5)                                                      # warm-up generations of the same searches
+        s.sync()
+        s.profile(True, 10)
+        t0 = time.perf_counter()
+        s.run(gens - 5)
+        s.sync()
+        dt = time.perf_counter() - t0
+        pr = s.profile_read()
+        costs, _ = s.results(problems)
+        hist[lazy] = np.stack([np.ascontiguousarray(s.trace(q)["bestL"], np.float32).view(np.uint32) for q in range(problems)])
+        fused_ms = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1)
+        s.close()
+        key = "lazy_" if lazy else ""
+        out[key + "problem_generations_per_s"] = problems * (gens - 5) / dt
+        out[key + "kernel_ms_per_generation"] = {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()}
+        if not lazy:
+            out["ms_per_generation_of_all"] = dt * 1e3 / (gens - 5)
+            out["in_loop_frac"] = problems * 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None
+            out["bytes_per_launch"] = problems * 48.0 * n ** 3
+            out["best_costs"] = [float(c) for c in costs]
+    out["lazy_identical_histories"] = bool(np.array_equal(hist[False], hist[True]))
+    return out
 
 
 def c5_full_extra(ctx):

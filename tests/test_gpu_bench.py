@@ -42,6 +42,7 @@ def test_bench_json_contract():
     ms = d["multi_start"]   # eight searches together on one GPU: more problem-generations/s than one alone, an HBM-resident sweep, all converge
     assert ms["problem_generations_per_s"] > 15000 and 0.4 < ms["in_loop_frac"] < 1.0
     assert ms["bytes_per_launch"] == 8 * 48.0 * 128 ** 3 and all(c == 378.0 for c in ms["best_costs"])
+    assert ms["lazy_identical_histories"] is True and ms["lazy_problem_generations_per_s"] > ms["problem_generations_per_s"]
     fr, c5 = d["full_run"], d["c5_full"]
     assert fr["generations"] == 500 and fr["best_cost"] == 378.0 and fr["generations_per_s"] > d["value"]
     assert c5["all_reached"] is True and c5["slots_by_rule"] * c5["batches"] >= 2016 and c5["t_pairs_s"] < 10
