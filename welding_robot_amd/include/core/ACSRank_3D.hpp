@@ -128,10 +128,11 @@ public:
     // what the last searchBestPathOfPoints did per shard (device, pairs, concurrent slots, batches, summed Manhattan length)
     struct ShardReport { int device; int pairs; int slots; int batches; long long weight; };
     const std::vector<ShardReport> &lastShards() const { return shard_report; }
-    // The pair loop (:472-499) is a loop over independent searches: in DEV mode it is sharded round-robin over
-    // these devices, one host thread + one wa_ctx (+ a replica of the grid) per entry.  Every pair keeps its GLOBAL
-    // index as stream key, so the cost matrix and the paths do not depend on the number of shards.  Default: every
-    // visible device (wa_device_count()).  An ordinal may be listed twice (two contexts on one GPU).
+    // The pair loop (:472-499) is a loop over independent searches: in DEV mode it is sharded over these devices, one host
+    // thread + one wa_ctx (+ a replica of the grid) per entry; the pairs are dealt longest-first (see searchBestPathOfPoints).
+    // Every pair keeps its GLOBAL index as stream key, so the cost matrix and the paths do not depend on the number of shards.
+    // Default: the primary context's device, then every other visible device (wa_device_count()).  An ordinal may be listed
+    // twice (two contexts on one GPU).
     void setDevices(const std::vector<int> &ordinals) { devices = ordinals; devices_set = true; }
     int lastStatus() const { return last_status; }
     const std::vector<float> &cost_matrix() const { return costs; }
