@@ -313,7 +313,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
                                              uint32_t evap_now,
                                              int32_t *__restrict__ path,
                                              int32_t *tab, int hash_log2, int32_t nx, int32_t nxy, int32_t n_vox,
-                                             int32_t path_cap, int32_t end, uint64_t antkey, int32_t *rng_r, int32_t &rng_f,
+                                             int32_t path_cap, int32_t end, uint64_t antkey, int32_t &rng_rs, int32_t &rng_f,
                                              int32_t &rng_b, int32_t spill_at, WaWalkState &st, int32_t *flags_out,
                                              unsigned long long *dbg, const int32_t *prefix_words)
 {
@@ -423,7 +423,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         } else {
             // no candidate (:162-166) returns before rand() is called: only draw when one exists
             if (admm == 0) { dead = true; break; }
-            rnd = (float)wa_glibc_next(rng_r, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
+            rnd = (float)wa_glibc_next_lanes(rng_rs, rng_f, rng_b) / 2147483648.0f;  // lockstep private copies
         }
         rnd *= total;                                  // :170
         const unsigned long long m2 = admm & __ballot(c >= rnd);  // :178
@@ -481,7 +481,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
 template <int MODE, bool SPARSE>
 __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, const float *pher, const float *heur,
                                           const uint32_t *stamp, float clean_info, uint32_t evap_now,
-                                          int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t *rng_r,
+                                          int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t &rng_rs,
                                           int32_t &rng_f, int32_t &rng_b, int32_t spill_at, WaWalkState &st,
                                           int32_t *flags_out)
 {
@@ -531,7 +531,7 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
         }
         int32_t r;
         if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
-        else r = wa_glibc_next(rng_r, rng_f, rng_b);
+        else r = wa_glibc_next_lanes(rng_rs, rng_f, rng_b);
         float rnd = (float)r / 2147483648.0f;
         rnd *= total;
         float prob = 0.f;
@@ -702,7 +702,7 @@ __device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
 template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
-                                            int hash_log2, int32_t *rng_r, int32_t &rng_f, int32_t &rng_b,
+                                            int hash_log2, int32_t &rng_rs, int32_t &rng_f, int32_t &rng_b,
                                             int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags,
                                             uint32_t best_ver, int32_t heur_slot)
 {
@@ -888,7 +888,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     }
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
-                                   rng_r, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
+                                   rng_rs, rng_f, rng_b, spill_at, st, flags_out, (slot == 0 && ant == 0) ? D.dbg : nullptr, prefix_words);
     else if (st.len >= (int32_t)D.path_cap) {  // cannot happen after a replay (the best path fits), kept for symmetry
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
         st.L = INFINITY;
@@ -897,7 +897,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         path[0] = start;  // the slow loop reads the path back from memory
     }
     WA_PHASE(9);
-    if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_r, rng_f, rng_b, spill_at, st, flags_out);
+    if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const int32_t colony = c->colony[gen & 1];
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
-    int32_t f = 0, b = 0;
+    int32_t f = 0, b = 0, rs_unused = 0;
     const float bestL = c->bestL;
     const int32_t rlen = (D.rtab && bestL != INFINITY) ? c->best_len : 0;
     // the rejoin watch pays once the colony has settled on the best path (it costs a failed attempt every few steps while the
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const unsigned long long t0_ = __builtin_readcyclecounter();
     if (slot == 0 && ant == 0 && threadIdx.x == 0 && D.dbg) atomicAdd(&D.dbg[5], t0_);
 #endif
-    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen, bestL,
+    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot);
 #ifdef WA_ANT_TIME
     if (threadIdx.x == 0 && D.dbg) {
@@ -1086,16 +1086,15 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     const WaSlotCtl *c = &D.ctl[slot];
     int32_t colony = c->colony[gen & 1];
     if (colony > D.max_colony) return;
-    // every lane keeps a private copy of the 31-word state: all lanes draw in lockstep, so the
-    // copies stay identical and no cross-lane traffic is needed
-    int32_t r[31];
-    for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
+    // the 31-word libc state lives in ONE register, word j in lane j; the two indices are wave-uniform (a per-lane copy of the
+    // array indexed by them compiles to a 31-way select chain per access: ~90 instructions per draw)
+    int32_t r = threadIdx.x < 31 ? D.rng->r[threadIdx.x] : 0;   // lane j holds word j of the state (see wa_glibc_next_lanes)
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
     for (int32_t ant = 0; ant < colony; ant++)
         wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);
+    if (threadIdx.x < 31) D.rng->r[threadIdx.x] = r;
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
         D.rng->b = b;
     }
@@ -1957,7 +1956,7 @@ __device__ __forceinline__ int wa_walk_replay26(const float *__restrict__ T, int
 
 template <int MODE>
 __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant, int32_t start,
-                                              int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t *rng_r,
+                                              int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t &rng_rs,
                                               int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen)
 {
     const int lane = threadIdx.x;
@@ -2153,7 +2152,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 25));
         int32_t r;
         if (MODE == 1) r = (int32_t)wa_ctr_draw(antkey, step);
-        else r = wa_glibc_next(rng_r, rng_f, rng_b);
+        else r = wa_glibc_next_lanes(rng_rs, rng_f, rng_b);
         float rnd = (float)r / 2147483648.0f;                                     // :169
         rnd *= total;
         const unsigned long long hit = __ballot(adm && c >= rnd);                 // first hit in descending edge order
@@ -2209,9 +2208,9 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
     const int32_t colony = c->colony[gen & 1];
     if (ant >= colony || colony > D.max_colony) return;
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
-    int32_t f = 0, b = 0;
+    int32_t f = 0, b = 0, rs_unused = 0;
     const int32_t rlen = (D.rtab && c->bestL != INFINITY) ? c->best_len : 0;
-    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, nullptr, f, b, &D.ctl[slot].flags, rlen);
+    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen);
 }
 
 __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
@@ -2221,14 +2220,13 @@ __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
     if (colony > D.max_colony) return;
-    int32_t r[31];
-    for (int i = 0; i < 31; i++) r[i] = D.rng->r[i];
+    int32_t r = threadIdx.x < 31 ? D.rng->r[threadIdx.x] : 0;   // lane j holds word j of the state (see wa_glibc_next_lanes)
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end;
     for (int32_t ant = 0; ant < colony; ant++)
         wa_walk_one26<0>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0);
+    if (threadIdx.x < 31) D.rng->r[threadIdx.x] = r;
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 31; i++) D.rng->r[i] = r[i];
         D.rng->f = f;
         D.rng->b = b;
     }

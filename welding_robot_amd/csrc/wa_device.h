@@ -104,6 +104,20 @@ __host__ __device__ inline int32_t wa_glibc_next(int32_t *r, int32_t &f, int32_t
     else if (++b >= 31) b = 0;
     return (int32_t)((v >> 1) & 0x7fffffffu);
 }
+#if defined(__HIPCC__)
+// the same generator with the state spread over the lanes of a wavefront: lane j < 31 holds r[j], f and b are wave-uniform.
+// r[f] += r[b]; result = r[f] >> 1 (random_r.c) as two v_readlane, one add and one v_writelane
+__device__ __forceinline__ int32_t wa_glibc_next_lanes(int32_t &rs, int32_t &f, int32_t &b)
+{
+    f = __builtin_amdgcn_readfirstlane(f);   // (uniform by construction; this tells the compiler)
+    b = __builtin_amdgcn_readfirstlane(b);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane(rs, f) + (uint32_t)__builtin_amdgcn_readlane(rs, b);
+    asm volatile("s_mov_b32 m0, %2\n s_nop 3\n v_writelane_b32 %0, %1, m0" : "+v"(rs) : "s"((int32_t)v), "s"(f) : "m0");
+    if (++f >= 31) { f = 0; ++b; }
+    else if (++b >= 31) b = 0;
+    return (int32_t)((v >> 1) & 0x7fffffffu);
+}
+#endif
 __host__ inline void wa_glibc_seed(WaGlibcRand *s, uint32_t seed)
 {
     if (seed == 0) seed = 1;
