@@ -207,7 +207,7 @@ def full_run_extra(solver, params, ids, wl, n, gens=500):
             "in_loop_frac": 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None}
 
 
-def live_traffic(n, ants, timeout_s=150):
+def live_traffic(n, ants, timeout_s=90):
     """HBM bytes per launch of the in-loop sweep launch, measured in THIS run: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as the guide's HBM section prescribes; 30 generations each),
     summed per kernel, FETCH_SIZE doubled (gfx950 tallies the 128-B requests of a 16-B/lane streaming read at 64 B).  Returns
