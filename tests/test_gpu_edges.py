@@ -298,3 +298,22 @@ def test_byte_rank_masks_equal_u64_rank_masks(ctx):
         assert np.array_equal(bits(ph), bits(a.pheromone())), key
         for q in range(2):
             assert np.array_equal(bits(slots[q][1]), bits(res[(False, "1")][q][1])), (key, q)
+
+
+def test_profile_can_stamp_the_sweep_launch_of_every_generation(ctx):
+    """wa_acs_profile(enable = 3): every n-th generation has all its launches stamped, the launch that carries the evaporation
+    sweep is stamped in EVERY generation (per-dispatch events, no extra stream operation)."""
+    og = box_grid(16, 16, 16, occ_prob=0.1, seed=2)
+    og.free[0] = og.free[-1] = 1
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, 1.0, 0)
+    s = api.AcsSolver(ctx, dg, 1, 16)
+    p = api.default_params(max_iteration=20, predict=60.0, fixed_colony=16, rng_mode=api.RNG_DEV, seed=4)
+    s.begin(p, 0, 16 ** 3 - 1)
+    s.profile(True, 10, sweep_every_generation=True)
+    s.run(20)
+    pr = s.profile_read()
+    assert pr["evaporate"]["launches"] == 20 and pr["walk"]["launches"] == 2 and pr["deposit"]["launches"] == 2
+    assert pr["evaporate"]["ms"] > 0
+    s.profile(True, 5)
+    s.run(0)
+    s.close()
