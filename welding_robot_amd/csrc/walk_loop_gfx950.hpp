@@ -19,7 +19,22 @@
 //     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
 //     dummy slot), limits are checked per 64-step block instead of per step.
 // Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
-#define WA_WALK_LDS_EXTRA 4160   // bytes behind the tabu hash: the sentinel slot (+ padding to 64 B), 64 dummy slots, 15 x 64 lane constants / diagnostic sums
+// bytes behind the tabu hash: the sentinel slot (+ padding to 64 B), 64 dummy slots, the lane-constant columns (7 of the dense loop +
+// 2 of the lazy / rejoin variants; the diagnostic builds put their six sums between them).  It counts: with a 2^12 table (pair planning)
+// a walk block is 16 KB + this, and 160 KB of LDS hold 8 of them only while this stays below 4 KB
+#if defined(WA_ASM_STAMPS) || defined(WA_ASM_SPAN_A)
+#define WA_WALK_LDS_EXTRA 4160
+#define WA_LC_COL_STAMP 13
+#define WA_LC_COL_PARAM 14
+#define WA_LC_OFF_STAMP "3328"
+#define WA_LC_OFF_PARAM "3584"
+#else
+#define WA_WALK_LDS_EXTRA 2624   // 64 + 256 + 9 x 256
+#define WA_LC_COL_STAMP 7
+#define WA_LC_COL_PARAM 8
+#define WA_LC_OFF_STAMP "1792"
+#define WA_LC_OFF_PARAM "2048"
+#endif
 #define WA_WALK_LDS_PAD 16       // entries between the table and the dummy slots; entry 0 of them is the sentinel (never empty, never a key)
 #define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
 #define WA_ASM_DPP_T " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i+1: total flows down into position 0
@@ -539,7 +554,7 @@
 #define WA_ASM_RUN_REJ(W)                                                                                         \
     asm volatile(                                                                                                 \
         WA_ASM_PROLOGUE                                                                                           \
-        "ds_read_b32 v94, %[lc] offset:3584\n"        /* lanes 3, 4: best-path version, hold-off */               \
+        "ds_read_b32 v94, %[lc] offset:" WA_LC_OFF_PARAM "\n"        /* lanes 3, 4: best-path version, hold-off */               \
         "s_waitcnt lgkmcnt(0)\n"                                                                                  \
         WA_ASM_REJ_INIT WA_ASM_LOOP_ALIGN                                                                         \
         "Lwa_top%=:\n"                                                                                            \
@@ -561,8 +576,8 @@
 #define WA_ASM_RUN_LAZY(STEP, W, REJINIT, REJEXITS)                                                                 \
     asm volatile(                                                                                                 \
         WA_ASM_PROLOGUE                                                                                           \
-        "ds_read_b32 v99, %[lc] offset:3328\n"        /* stamp offset of this lane's neighbour */                 \
-        "ds_read_b32 v94, %[lc] offset:3584\n"        /* lanes 0..2: clean value, evap_now + 1, rho; 3, 4: version, hold-off */ \
+        "ds_read_b32 v99, %[lc] offset:" WA_LC_OFF_STAMP "\n"        /* stamp offset of this lane's neighbour */                 \
+        "ds_read_b32 v94, %[lc] offset:" WA_LC_OFF_PARAM "\n"        /* lanes 0..2: clean value, evap_now + 1, rho; 3, 4: version, hold-off */ \
         "v_mov_b32 v96, %[sio]\n"                                                                                 \
         "s_waitcnt lgkmcnt(0)\n"                                                                                  \
         "v_readlane_b32 s33, v94, 0\n"                                                                            \
@@ -629,11 +644,11 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
         lc[6 * 64 + lane] = (table + WA_WALK_LDS_PAD + lane) * 4;                    // this lane's dummy slot
         if (LAZY) {
-            lc[13 * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
+            lc[WA_LC_COL_STAMP * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
         }
         // column 14, lanes 0..2: clean value, evap_now + 1, rho (lazy field); lanes 3, 4: best-path version, hold-off (rejoin watch)
         if (LAZY || REJOIN)
-            lc[14 * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
+            lc[WA_LC_COL_PARAM * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
                                  : lane == 3 ? (int32_t)ver : hold_off;
     }
     const int32_t lcaddr = (table + WA_WALK_LDS_PAD + 64 + lane) * 4;
