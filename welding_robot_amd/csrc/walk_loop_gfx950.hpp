@@ -19,9 +19,10 @@
 //     new voxel id come out of ONE v_readlane, the tabu insert is an unconditional ds_write (other lanes hit a private
 //     dummy slot), limits are checked per 64-step block instead of per step.
 // Lane constants travel through LDS (inline asm takes at most 30 operands); temporaries are fixed registers.
-// bytes behind the tabu hash: the sentinel slot (+ padding to 64 B), 64 dummy slots, the lane-constant columns (7 of the dense loop +
-// 2 of the lazy / rejoin variants; the diagnostic builds put their six sums between them).  It counts: with a 2^12 table (pair planning)
-// a walk block is 16 KB + this, and 160 KB of LDS hold 8 of them only while this stays below 4 KB
+// bytes behind the tabu hash: the sentinel slot (+ padding to 64 B), 64 dummy slots and two columns of 64 dwords that carry the lazy /
+// rejoin variants' per-lane stamp offsets and scalars into the loop (the seven lane constants of every variant travel as operands; the
+// diagnostic builds keep their six sums in further columns).  It counts: with a 2^12 table (pair planning) a walk block is 16 KB + this,
+// and 160 KB of LDS hold NINE of them while this stays below 1 820 B (eight below 4 096 B)
 #if defined(WA_ASM_STAMPS) || defined(WA_ASM_SPAN_A)
 #define WA_WALK_LDS_EXTRA 4160
 #define WA_LC_COL_STAMP 13
@@ -29,11 +30,11 @@
 #define WA_LC_OFF_STAMP "3328"
 #define WA_LC_OFF_PARAM "3584"
 #else
-#define WA_WALK_LDS_EXTRA 2624   // 64 + 256 + 9 x 256
-#define WA_LC_COL_STAMP 7
-#define WA_LC_COL_PARAM 8
-#define WA_LC_OFF_STAMP "1792"
-#define WA_LC_OFF_PARAM "2048"
+#define WA_WALK_LDS_EXTRA 832    // 64 + 256 + 2 x 256
+#define WA_LC_COL_STAMP 0
+#define WA_LC_COL_PARAM 1
+#define WA_LC_OFF_STAMP "0"
+#define WA_LC_OFF_PARAM "256"
 #endif
 #define WA_WALK_LDS_PAD 16       // entries between the table and the dummy slots; entry 0 of them is the sentinel (never empty, never a key)
 #define WA_ASM_DPP_C " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   // lane i <- lane i-1: prob_sum grows from role 5 (position 0) upwards
@@ -407,13 +408,13 @@
 
 // the pieces of the loop's assembly text that the dense and the lazy variant share
 #define WA_ASM_PROLOGUE                                                                                           \
-    "ds_read_b32 v64, %[lc]\n"                                                                                    \
-    "ds_read_b32 v65, %[lc] offset:256\n"                                                                         \
-    "ds_read_b32 v66, %[lc] offset:512\n"                                                                         \
-    "ds_read_b32 v67, %[lc] offset:768\n"                                                                         \
-    "ds_read_b32 v68, %[lc] offset:1024\n"                                                                        \
-    "ds_read_b32 v69, %[lc] offset:1280\n"                                                                        \
-    "ds_read_b32 v70, %[lc] offset:1536\n"                                                                        \
+    "v_mov_b32 v64, %[c0]\n"                     /* the seven lane constants: lane, record offset, touch offset, hash term, */ \
+    "v_mov_b32 v65, %[c1]\n"                     /* neighbour offset, path-word term, dummy slot (see wa_walk_fast_asm) */      \
+    "v_mov_b32 v66, %[c2]\n"                                                                                      \
+    "v_mov_b32 v67, %[c3]\n"                                                                                      \
+    "v_mov_b32 v68, %[c4]\n"                                                                                      \
+    "v_mov_b32 v69, %[c5]\n"                                                                                      \
+    "v_mov_b32 v70, %[c6]\n"                                                                                      \
     "v_mov_b32 v71, %[pio]\n"                                                                                     \
     "v_mov_b32 v72, %[hio]\n"                                                                                     \
     "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
@@ -548,7 +549,7 @@
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_TAIL                                                                                               \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
-        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))                    \
         : WA_ASM_CLOBBERS);
 #define WA_ASM_RUN_REJ(W)                                                                                         \
@@ -568,7 +569,7 @@
         WA_ASM_REJ_EXITS                                                                                          \
         WA_ASM_TAIL                                                                                               \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
-        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark)  \
         : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 // the lazy-field loop as a statement (STEP = WA_ASM_STEP_LAZY or WA_ASM_STEP_LAZY_REJ; REJINIT / REJEXITS = the rejoin watch's
@@ -604,7 +605,7 @@
         WA_ASM_TAIL                                                                                               \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), \
           [sio] "+v"(pd)                                                                                          \
-        : [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b), [markb] "s"(mark) \
         : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 
@@ -634,22 +635,20 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
     const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
     const char *stamp_b = LAZY ? reinterpret_cast<const char *>(stamp) - stamp_guard_bytes : nullptr;
-    {   // lane constants (columns of 64 dwords behind the dummy slots)
+    // lane constants of the loop (operands; the loop copies them into its fixed registers v64..v70)
+    const int32_t c0 = lane;
+    const int32_t c1 = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
+    const int32_t c2 = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
+    const int32_t c3 = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
+    const int32_t c4 = dk;
+    const int32_t c5 = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
+    const int32_t c6 = (table + WA_WALK_LDS_PAD + lane) * 4;                    // this lane's dummy slot
+    if (LAZY || REJOIN) {   // two columns of 64 dwords behind the dummy slots
         int32_t *lc = tab + table + WA_WALK_LDS_PAD + 64;
-        lc[0 * 64 + lane] = lane;
-        lc[1 * 64 + lane] = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
-        lc[2 * 64 + lane] = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
-        lc[3 * 64 + lane] = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
-        lc[4 * 64 + lane] = dk;
-        lc[5 * 64 + lane] = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
-        lc[6 * 64 + lane] = (table + WA_WALK_LDS_PAD + lane) * 4;                    // this lane's dummy slot
-        if (LAZY) {
-            lc[WA_LC_COL_STAMP * 64 + lane] = dj * 4 + stamp_guard_bytes;                         // stamp of neighbour j
-        }
-        // column 14, lanes 0..2: clean value, evap_now + 1, rho (lazy field); lanes 3, 4: best-path version, hold-off (rejoin watch)
-        if (LAZY || REJOIN)
-            lc[WA_LC_COL_PARAM * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
-                                 : lane == 3 ? (int32_t)ver : hold_off;
+        if (LAZY) lc[WA_LC_COL_STAMP * 64 + lane] = dj * 4 + stamp_guard_bytes;   // stamp of neighbour j
+        // lanes 0..2: clean value, evap_now + 1, rho (lazy field); lanes 3, 4: best-path version, hold-off (rejoin watch)
+        lc[WA_LC_COL_PARAM * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
+                                          : lane == 3 ? (int32_t)ver : hold_off;
     }
     const int32_t lcaddr = (table + WA_WALK_LDS_PAD + 64 + lane) * 4;
     int32_t cur = st.cur, len = st.len, g8 = 0;
