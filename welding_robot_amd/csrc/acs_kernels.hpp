@@ -1012,16 +1012,19 @@ __global__ __launch_bounds__(256) void k_replay_table(WaAcsDev D, WaRun R)
 // table rows that also apply the deposits on every edge leaving a best-path node -- the only values
 // the table depends on -- and blocks [TB, TB + 8*64) are the ordinary apply pass, which skips exactly
 // those edges.  The two roles touch disjoint edges, so no ordering between them is needed.
-#define WA_TABLE_BLOCKS 32
+// table blocks: the host passes 64 for one or a few searches (1024 rows: the 800-1 300-node best paths of the exploratory generations get a
+// row each; measured on the driver's command: 32 blocks 5 358 gen/s, 64 5 432, 96 5 351; no difference once converged) and 32 for launches
+// that carry 32 searches or more (C5 with 224: 0.535 s against 0.540)
+#define WA_TABLE_BLOCKS_MAX 64
 // split_log2: apply blocks per depositing rank = 1 << this (the host passes 2 for one or a few searches -- 8 blocks per rank are no
 // faster --, 1 for launches that carry 32 searches or more)
-__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_t split_log2)
+__global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_t split_log2, int32_t table_blocks)
 {
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y;
     // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
     if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
-    if ((int32_t)blockIdx.x < WA_TABLE_BLOCKS) {
+    if ((int32_t)blockIdx.x < table_blocks) {
         // independent loads first: deposit coefficients, control block, this row's path words
         const int32_t tid = threadIdx.x, row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
         const float dep_mine = (tid < 64 && tid < D.max_colony) ? D.depA[(int64_t)slot * D.max_colony + tid] : 0.f;
@@ -1030,10 +1033,10 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
         const int32_t n_dep = D.ctl[slot].n_dep;
         if (tid < 64) s_dep[tid] = tid < n_dep ? dep_mine : 0.f;
         __syncthreads();
-        wa_table_rows(D, R, slot, row0, (WA_TABLE_BLOCKS * blockDim.x) >> 4, true, s_dep, w0, w1);
+        wa_table_rows(D, R, slot, row0, (table_blocks * blockDim.x) >> 4, true, s_dep, w0, w1);
         return;
     }
-    const int32_t ab = (int32_t)blockIdx.x - WA_TABLE_BLOCKS;  // 0..(ranks << split_log2)-1: (bx, rank bit)
+    const int32_t ab = (int32_t)blockIdx.x - table_blocks;  // 0..(ranks << split_log2)-1: (bx, rank bit)
     wa_apply_body<6>(D, slot, 0, ab >> split_log2, ab & ((1 << split_log2) - 1), 1 << split_log2, true, s_dep);
 }
 
