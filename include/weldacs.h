@@ -194,17 +194,7 @@ enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_
 /* enable: 0 off; 1 every sample_every-th generation has all its launches stamped; 3 = the same, and the launch that carries the
  * evaporation sweep is stamped in EVERY generation (per-dispatch start/stop events of hipExtLaunchKernelGGL: no extra stream
  * operation, so the timed loop is not perturbed -- what bench.py's roofline figure uses) */
-/* One or a few dense 6-neighbour DEV searches per GPU run their generations as TWO launches (k_generation: walk beside the
- * evaporation sweep, then rank + mark; k_apply_table), everything else as three (walk; sweep + rank + mark; apply + table) -- same
- * results bit for bit.  A sampled generation (and every generation under enable & 2) runs as three launches so that the classes
- * below keep their meaning, unless enable & 4: then the loop is sampled as it runs -- WA_K_WALK = the k_generation launch (walk,
- * sweep, rank and mark), WA_K_EVAPORATE stays empty, WA_K_DEPOSIT = apply + table.  WA_OVERLAP=0 in the environment (read at
- * wa_acs_create) keeps a solver on three launches, which is what a GPU shared with other work should use: the mark blocks of
- * k_generation wait for the search's ants on their CUs, and if those have not arrived after 0.2 s (another kernel holding the
- * CUs) the run is abandoned and wa_acs_sync returns WA_ERR_STATE. */
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
-/* generations enqueued since wa_acs_create, and how many of them ran as the two-launch loop */
-int wa_acs_loop_info(wa_acs *s, int64_t *generations, int64_t *generations_overlapped);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
 /* diagnostic cycle counters of the walk's inner loop: all zero unless the library was built with
  * -DWA_STAMPS (tools/walk_stamps.py); never enabled in the product build */

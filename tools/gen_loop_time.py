@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Per-launch times of the generation loop as it runs (HIP events around every launch of every generation, so the loop itself is
-slower than untimed): BASELINE config C3, generations 0-19 (exploratory) and 200-499 (converged).
+"""Per-launch times of the generation loop (HIP events around every launch of every generation, so the loop itself is slower than
+untimed): BASELINE config C3, generations 0-19 (exploratory) and 200-499 (converged).
 
-    python tools/gen_loop_time.py            (WA_OVERLAP=0 for the three-launch loop)"""
+    python tools/gen_loop_time.py"""
 import os
 import sys
 import time
@@ -27,7 +27,7 @@ def main():
         solver.begin(p, ids[0], ids[1], streams=[0])
         ctx.sync()
         for label, gens, timed in (("generations 0-19", 20, True), ("20-199", 180, False), ("200-499", 300, True)):
-            solver.profile(timed, 1, as_it_runs=True)
+            solver.profile(timed, 1)
             t0 = time.perf_counter()
             solver.run(gens)
             solver.sync()
@@ -36,7 +36,7 @@ def main():
                 r = solver.profile_read()
                 print("%-18s wall %7.1f us/generation   " % (label, dt / gens * 1e6) +
                       "  ".join("%s %.1f us x %d" % (k, v["ms"] / max(1, v["launches"]) * 1e3, v["launches"]) for k, v in r.items() if v["launches"]))
-    print("loop_info (generations, overlapped):", solver.loop_info(), " best:", solver.results(1)[0])
+    print("best:", solver.results(1)[0])
 
 
 if __name__ == "__main__":

@@ -267,18 +267,8 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))
         return c.value, np.float32(l.value), np.float32(q.value)
 
-    def profile(self, enable=True, sample_every=1, sweep_every_generation=False, as_it_runs=False):
-        """HIP-event timing of sampled generations.  A sampled generation runs as three launches (walk; sweep + rank + mark;
-        apply + table) whatever loop the solver otherwise uses; as_it_runs=True samples the two-launch loop as it is
-        (walk = the k_generation launch, evaporate empty) -- see wa_acs_profile in include/weldacs.h"""
-        mode = ((3 if sweep_every_generation else 1) | (4 if as_it_runs else 0)) if enable else 0
-        self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, mode, sample_every))
-
-    def loop_info(self):
-        """(generations enqueued since creation, how many of them ran as the two-launch overlapped loop)"""
-        g, o = C.c_int64(), C.c_int64()
-        self.ctx.check(self.ctx.lib.wa_acs_loop_info(self.h, C.byref(g), C.byref(o)))
-        return g.value, o.value
+    def profile(self, enable=True, sample_every=1, sweep_every_generation=False):
+        self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, (3 if sweep_every_generation else 1) if enable else 0, sample_every))
 
     def profile_read(self):
         ms = np.zeros(L.K_COUNT, np.float64)

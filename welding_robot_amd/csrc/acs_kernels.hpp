@@ -55,22 +55,10 @@ struct WaAcsDev {
     uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
-    int32_t *done;                 // [slot] ants of the running generation that have finished (k_generation's ticket counter; 0 at rest)
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
 };
-
-// An ant's results (cost, node count, path words) are read by the rank + mark wavefronts of the SAME launch when a generation runs
-// as k_generation, possibly on another XCD whose L2 is not coherent with the writer's: they are stored write-through (agent-scope
-// relaxed atomics = `sc1` stores) and read the same way, so that publishing them needs no L2 write-back / invalidate -- with 256 ants
-// finishing one by one those fences cost the still-walking ants of the XCD their cached records (measured: +19 us per exploratory
-// launch, +28 us per converged one).  The walk kernels of the three-launch loop use the same stores (write-only data, no cost).
-template <class T> __device__ __forceinline__ void wa_st_pub(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool COH, class T> __device__ __forceinline__ T wa_ld_pub(const T *p)
-{
-    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
 
 // rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
 struct WaMaskRef {
@@ -191,7 +179,6 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.flags = 0;
     wa_next_params(c, R, 0);
     D.ctl[slot] = c;
-    D.done[slot] = 0;
 }
 
 
@@ -461,7 +448,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(pbuf) : "s"(word), "s"(sel) : "m0");
         }
         if (__builtin_expect((len & 63) == 63, 0))     // block full: one coalesced store
-            wa_st_pub(&path[(len & ~63) + lane], pbuf);
+            path[(len & ~63) + lane] = pbuf;
         len++;
         L += R.precision;                              // :78, distance == precision (:378)
         WA_STAMP(6);                                   // path capture, counters
@@ -483,7 +470,7 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
         st.done = true;
     }
     if (len & 63) {  // partial last block (entries [len & ~63, len))
-        if (lane < (len & 63)) wa_st_pub(&path[(len & ~63) + lane], pbuf);
+        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
     }
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
 }
@@ -564,7 +551,7 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
             break;
         }
         if (lane == 0) {
-            wa_st_pub(&path[len], next | (pick << WA_K_SHIFT));
+            path[len] = next | (pick << WA_K_SHIFT);
             tabu_insert(T, next);
         }
         __builtin_amdgcn_wave_barrier();
@@ -753,7 +740,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int32_t q = u * 64 + lane;
-            if (q < st.len) wa_st_pub(&path[q], w0[u]);
+            if (q < st.len) path[q] = w0[u];
         }
         for (int32_t q0 = 512; q0 < st.len; q0 += 512) {
             int32_t w[8];
@@ -765,15 +752,15 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int32_t q = q0 + u * 64 + lane;
-                if (q < st.len) wa_st_pub(&path[q], w[u]);
+                if (q < st.len) path[q] = w[u];
             }
         }
         if (what != 3) {  // finished on the replay track
             // arriving over the whole best path accumulates exactly the steps that produced best.L
             const float L = what == 2 ? bestL : INFINITY;
             if (lane == 0) {
-                wa_st_pub(&D.antL[(int64_t)slot * D.max_colony + ant], L);
-                wa_st_pub(&D.antLen[(int64_t)slot * D.max_colony + ant], st.len);
+                D.antL[(int64_t)slot * D.max_colony + ant] = L;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
             }
             return;
         }
@@ -856,7 +843,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                 gained = stop - q;
                 for (int32_t t = lane; t < gained; t += 64) {     // the ant walked best[q+1 .. stop]: path words (:76-77) and tabu set (:75)
                     const int32_t w = bpath[q + 1 + t];
-                    wa_st_pub(&path[st.len + t], w);
+                    path[st.len + t] = w;
                     const int32_t key = w & (int32_t)WA_ID_MASK;
                     uint32_t hh = ((uint32_t)key * 2654435761u) >> T.shift;
                     while (atomicCAS(&tab[hh], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) hh = (hh + 1) & T.mask;
@@ -907,13 +894,13 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         st.L = INFINITY;
         st.done = true;
     } else if (!prefix_words && lane == 0) {
-        wa_st_pub(&path[0], start);  // the slow loop reads the path back from memory
+        path[0] = start;  // the slow loop reads the path back from memory
     }
     WA_PHASE(9);
     if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out);
     if (lane == 0) {
-        wa_st_pub(&D.antL[(int64_t)slot * D.max_colony + ant], st.L);
-        wa_st_pub(&D.antLen[(int64_t)slot * D.max_colony + ant], st.len);
+        D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
+        D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
     }
 }
 
@@ -1037,7 +1024,6 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
     const int32_t slot = blockIdx.y;
     // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
     if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) D.done[slot] = 0;   // the ticket counter of k_generation, for the next generation
     if ((int32_t)blockIdx.x < table_blocks) {
         // independent loads first: deposit coefficients, control block, this row's path words
         const int32_t tid = threadIdx.x, row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1061,8 +1047,9 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 // the first generations of a search, in which the watch cannot be armed yet (it waits for a best path that has been stable for
 // WA_REENTRY_STABLE generations): the mere presence of that code costs the exploratory walk 1.5 % (187 vs 190 us per launch).
 template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
-__device__ __forceinline__ void wa_walk_block(const WaAcsDev &D, const WaRun &R, int hash_log2, int32_t gen, int32_t walk_flags, int32_t *lds)
+__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
+    extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
@@ -1091,13 +1078,6 @@ __device__ __forceinline__ void wa_walk_block(const WaAcsDev &D, const WaRun &R,
         atomicAdd(&D.dbg[3], n);
     }
 #endif
-}
-
-template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
-__global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
-{
-    extern __shared__ int32_t lds[];
-    wa_walk_block<ALPHA1, SPARSE, WARM, REJ>(D, R, hash_log2, gen, walk_flags, lds);
 }
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
@@ -1377,49 +1357,17 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 // :268-272 -- dst = src * rho over n_floats values; float4 per lane, 4 independent float4 in flight per
 // thread, grid-stride over E blocks.  One definition for k_evaporate and the fused k_evap_rank_mark.
 typedef float wa_v4f __attribute__((ext_vector_type(4)));
-#if defined(WA_EXP_LD_BITS) || defined(WA_EXP_ST_BITS)   // experiments: cache-control bits on the sweep's accesses (0 none, 1 sc1, 2 sc0 sc1, 3 nt, 4 sc0)
-#define WA_EXP_BITS_0 ""
-#define WA_EXP_BITS_1 "sc1"
-#define WA_EXP_BITS_2 "sc0 sc1"
-#define WA_EXP_BITS_3 "nt"
-#define WA_EXP_BITS_4 "sc0"
-#ifndef WA_EXP_LD_BITS
-#define WA_EXP_LD_BITS 0
-#endif
-#ifndef WA_EXP_ST_BITS
-#define WA_EXP_ST_BITS 0
-#endif
-#define WA_EXP_CAT2(a, b) a##b
-#define WA_EXP_CAT(a, b) WA_EXP_CAT2(a, b)
-#define WA_EXP_SWEEP_LD WA_EXP_CAT(WA_EXP_BITS_, WA_EXP_LD_BITS)
-#define WA_EXP_SWEEP_ST WA_EXP_CAT(WA_EXP_BITS_, WA_EXP_ST_BITS)
-__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p)
-{
-    wa_v4f v;
-    asm volatile("global_load_dwordx4 %0, %1, off " WA_EXP_SWEEP_LD "\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v) { asm volatile("global_store_dwordx4 %0, %1, off " WA_EXP_SWEEP_ST :: "v"(p), "v"(v) : "memory"); }
-#else
 __device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p) { return *p; }
 __device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v) { *p = v; }
-#endif
-__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E, int32_t bdim, int32_t tid)
+__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
 {
     const wa_v4f *s4 = reinterpret_cast<const wa_v4f *>(src);
     wa_v4f *d4 = reinterpret_cast<wa_v4f *>(dst);
     const int64_t n4 = n_floats >> 2;
-    const int64_t gsz = (int64_t)E * bdim;
-    int64_t i = (int64_t)ebx * bdim + tid;
+    const int64_t gsz = (int64_t)E * blockDim.x;
+    int64_t i = (int64_t)ebx * blockDim.x + threadIdx.x;
     for (; i + 3 * gsz < n4; i += 4 * gsz) {
-#if defined(WA_EXP_LD_BITS) || defined(WA_EXP_ST_BITS)
-        wa_v4f a, b, c, d;
-        asm volatile("global_load_dwordx4 %0, %4, off " WA_EXP_SWEEP_LD "\n global_load_dwordx4 %1, %5, off " WA_EXP_SWEEP_LD "\n"
-                     "global_load_dwordx4 %2, %6, off " WA_EXP_SWEEP_LD "\n global_load_dwordx4 %3, %7, off " WA_EXP_SWEEP_LD "\n s_waitcnt vmcnt(0)"
-                     : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(s4 + i), "v"(s4 + i + gsz), "v"(s4 + i + 2 * gsz), "v"(s4 + i + 3 * gsz) : "memory");
-#else
         wa_v4f a = wa_sweep_ld(s4 + i), b = wa_sweep_ld(s4 + i + gsz), c = wa_sweep_ld(s4 + i + 2 * gsz), d = wa_sweep_ld(s4 + i + 3 * gsz);
-#endif
         a *= rho; b *= rho; c *= rho; d *= rho;
         wa_sweep_st(d4 + i, a); wa_sweep_st(d4 + i + gsz, b); wa_sweep_st(d4 + i + 2 * gsz, c); wa_sweep_st(d4 + i + 3 * gsz, d);
     }
@@ -1429,163 +1377,8 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
         wa_sweep_st(d4 + i, a);
     }
     // tail (n_floats is even; at most 2 floats)
-    const int64_t t = (n4 << 2) + (int64_t)ebx * bdim + tid;
+    const int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + threadIdx.x;
     if (t < n_floats) dst[t] = src[t] * rho;
-}
-__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
-{
-    wa_sweep_body(src, dst, n_floats, rho, ebx, E, (int32_t)blockDim.x, (int32_t)threadIdx.x);
-}
-
-
-// ------------------------------------------------------------------ rank + publish + mark
-// rank + publish + mark of one (slot, generation) by "mark block" mb of the launch: nthr threads (tid = 0..nthr-1) that share the LDS
-// arrays of L and synchronise through SYNC().  Used by the fused post-walk launch (a 256-thread block, __syncthreads) and by the
-// overlapped generation launch (the first four wavefronts of a walk block, an LDS counter barrier: k_generation).
-struct WaRankLds {
-    unsigned long long *keys;   // [cmax]
-    int32_t *perm, *len;        // [cmax]
-    int32_t *ndep, *fin;
-    unsigned long long *steps;
-};
-template <bool SPARSE, int NB, bool COH, class SYNC>
-__device__ __forceinline__ void wa_rank_mark(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t gen, int32_t mb, int32_t split_log2,
-                                             float *dst_base, int32_t tid, int32_t nthr, const WaRankLds &L, SYNC sync)
-{
-    WaSlotCtl *ctl = &D.ctl[slot];
-    const int32_t colony = ctl->colony[gen & 1];
-    const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
-    const float *antL = D.antL + (int64_t)slot * D.max_colony;
-    const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
-    unsigned long long *s_keys = L.keys;
-    int32_t *s_perm = L.perm, *s_len = L.len;
-    int32_t &s_ndep = *L.ndep, &s_fin = *L.fin;
-    unsigned long long &s_steps = *L.steps;
-    if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
-    // This block is a chain of dependent global loads beside a sweep that saturates the memory system (every level costs 2-3 us there):
-    // the ants' results are requested for ALL max_colony ants before the control block says how many there are (inside the allocation;
-    // entries beyond the colony are never looked at), and every ant's length goes to LDS with its key, so that the ranked ant's length is
-    // an LDS read: control block + results -> path words -> marks, three levels instead of five.
-    const int32_t cmax = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
-    for (int32_t a = tid; a < cmax; a += nthr) {
-        const float La = wa_ld_pub<COH>(&antL[a]);
-        const int32_t na = wa_ld_pub<COH>(&antLen[a]);
-        s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
-        s_len[a] = na;
-    }
-    if (colony > D.max_colony || colony > WA_RANK_LDS) {
-        if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
-        return;
-    }
-    sync();
-    int32_t myfin = 0;
-    unsigned long long mysteps = 0;
-    if (mb == 0)
-        for (int32_t a = tid; a < colony; a += nthr) {
-            myfin += (__uint_as_float((uint32_t)(s_keys[a] >> 32)) != INFINITY) ? 1 : 0;
-            mysteps += (unsigned long long)(s_len[a] - 1);
-        }
-    for (int32_t a = tid; a < colony; a += nthr) {  // ascending (L, ant) by counting (:273-275, DEV tie rule)
-        const unsigned long long ka = s_keys[a];
-        int32_t r = 0;
-#pragma unroll 8
-        for (int32_t b = 0; b < colony; b++) r += s_keys[b] < ka ? 1 : 0;
-        s_perm[r] = a;
-        const int32_t o = r + 1;
-        const float La = __uint_as_float((uint32_t)(ka >> 32));
-        const bool ok = !(La == INFINITY || (float)o > lambda - 1);  // :200
-        if (ok) atomicMax(&s_ndep, o);
-        if (mb == 0) {  // publish for the apply pass
-            D.perm[(int64_t)slot * D.max_colony + r] = a;
-            D.depA[(int64_t)slot * D.max_colony + r] = ok ? (lambda - (float)o) * Q / La : 0.f;  // :211
-        }
-    }
-    if (mb == 0) {
-        for (int o = 32; o > 0; o >>= 1) { myfin += __shfl_down(myfin, o, 64); mysteps += __shfl_down(mysteps, o, 64); }
-        if ((tid & 63) == 0) { atomicAdd(&s_fin, myfin); atomicAdd(&s_steps, mysteps); }
-    }
-    sync();
-    const int32_t n_dep = s_ndep;
-    if (mb == 0) {  // ---- publish: iteration best -> global best (:263-264), trace, next parameters (:247-249)
-        float iterL = INFINITY;
-        int32_t iterAnt = -1;
-        if (colony > 0) { iterAnt = s_perm[0]; iterL = __uint_as_float((uint32_t)(s_keys[iterAnt] >> 32)); }  // rank 1 = first ant with the minimal L
-        float bestL = ctl->bestL;
-        uint32_t ver = ctl->best_ver;
-        int32_t blen = ctl->best_len;
-        bool changed = false;
-        if (iterAnt >= 0 && iterL < bestL) {
-            blen = s_len[iterAnt];
-            const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
-            int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
-            uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
-            int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
-            ver = ver + 1;
-            for (int32_t i = tid; i < blen; i += nthr) {
-                int32_t w = wa_ld_pub<COH>(&srcp[i]);
-                dstp[i] = w;
-                mark[w & WaNbT<NB>::IDM] = ver;
-                pos[w & WaNbT<NB>::IDM] = i;
-            }
-            bestL = iterL;
-            changed = true;
-        }
-        if (tid == 0) {
-            if (gen < D.trace_cap) {
-                int64_t t = (int64_t)slot * D.trace_cap + gen;
-                D.trBest[t] = bestL;
-                D.trIter[t] = iterL;
-                D.trColony[t] = colony;
-                D.trFinite[t] = s_fin;
-                D.trSteps[t] = (long long)s_steps;
-            }
-            // written in place, field by field (a local copy indexed by the generation's parity would live in scratch memory);
-            // nothing a sibling block reads during this launch changes: [gen&1] slots, start/end/stream
-            ctl->bestL = bestL;
-            ctl->best_len = blen;
-            ctl->best_ver = ver;
-            ctl->dep_lambda = lambda;
-            ctl->dep_Q = Q;
-            ctl->dep_bestL = bestL;
-            ctl->n_dep = n_dep;
-            ctl->gen = gen + 1;
-            if (changed) ctl->tabu_gen = gen;   // the replay-table rows of this generation rebuild the prefix-tabu bits
-            ctl->clean[(gen + 1) & 1] = ctl->clean[gen & 1] * R.rho;   // what one more evaporation makes of a never-deposited edge
-            wa_next_params(*ctl, R, (gen + 1) & 1);
-        }
-    }
-    // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
-    const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
-    if (o > n_dep) return;
-    const int32_t a = s_perm[o - 1];
-    const int32_t len = s_len[a];
-    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
-    const WaMaskRef mask = wa_mask_of(D, slot);
-    float *ph = dst_base + (int64_t)slot * D.pher_stride;
-    const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
-    for (int32_t i = 1 + bx * nthr + tid; i < len; i += (nthr << split_log2)) {
-        int32_t w = wa_ld_pub<COH>(&path[i]);
-        int32_t v = wa_ld_pub<COH>(&path[i - 1]) & WaNbT<NB>::IDM;
-        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
-        wa_mask_or(mask, e, bit);
-        if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
-            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
-            const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;
-            const uint32_t old = atomicExch(&stamp[v], target);
-            if (old == 0) {            // first deposit ever: v joins the dirty list, its record is written at the clean value
-                const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
-                D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
-                    const float st0 = ph[(int64_t)v * 6 + k];
-                    ph[(int64_t)v * 6 + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
-                }
-            } else if (old != target) {   // deposited before: apply the evaporations it has missed since
-#pragma unroll
-                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, R.rho);
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------ fused post-walk launch (DEV mode)
@@ -1638,117 +1431,141 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         return;
     }
     // ---- rank + mark
+    const int32_t mb = (int32_t)blockIdx.x;  // 0..511: (bx = mb & 7, rank bit = mb >> 3)
+    WaSlotCtl *ctl = &D.ctl[slot];
+    const int32_t colony = ctl->colony[gen & 1];
+    const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
+    const float *antL = D.antL + (int64_t)slot * D.max_colony;
+    const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
     __shared__ unsigned long long s_keys[WA_RANK_LDS];
     __shared__ int32_t s_perm[WA_RANK_LDS], s_len[WA_RANK_LDS];
     __shared__ int32_t s_ndep, s_fin;
     __shared__ unsigned long long s_steps;
-    WaRankLds L;
-    L.keys = s_keys; L.perm = s_perm; L.len = s_len; L.ndep = &s_ndep; L.fin = &s_fin; L.steps = &s_steps;
-    wa_rank_mark<SPARSE, NB, false>(D, R, slot, gen, (int32_t)blockIdx.x, split_log2, dst_base, tid, (int32_t)blockDim.x, L, [] { __syncthreads(); });
-}
-
-// ------------------------------------------------------------------ the overlapped generation launch
-// walk || sweep, then rank + mark, in ONE launch (dense field, 6 neighbours, DEV mode, alpha == 1, every walk block on a CU of its
-// own -- the latency-bound regime of one or a few searches per GPU; the host falls back to walk -> k_evap_rank_mark otherwise):
-//   * blocks of 16 wavefronts.  Wavefront 0 walks the block's ant exactly as k_walk_dev does.  Wavefronts 4..15 of EVERY block are the
-//     evaporation sweep (dst = src * rho does not depend on the walk): it runs beside the walk instead of after it.  Measured at C3
-//     (tools/exp_overlap.sh at the commit that introduced this kernel, profiles/r03/overlap.txt): the sweep costs the longest ant
-//     5-7 us whatever the sweep's intensity (1, 3, 7 or 15 sweeping wavefronts per CU; idle extra wavefronts cost nothing; non-temporal
-//     sweep loads or stores make it worse) against the 16-17 us of a sweep launched after the walk, and a converged generation's
-//     replay walk (5.5 us) disappears under the sweep (15.5 us for both).
-//   * a walking wavefront that is done publishes its results (release fence) and takes a ticket.  Wavefronts 0..3 of the first MB
-//     blocks stay behind as the "mark blocks" of k_evap_rank_mark: wavefront 0 polls the ticket counter until every ant of the search
-//     has arrived, wakes wavefronts 1..3 through an LDS word, and the four of them (256 threads, LDS barrier of their own -- the
-//     sweeping wavefronts of the block are elsewhere) run wa_rank_mark on the block's LDS, which the walk no longer needs.
-//   * waiting blocks hold their CU.  That is safe because the launch is co-resident by construction (at most one block per CU, the
-//     host checks) -- and if another kernel holds CUs for so long that the ants are not done after WA_GEN_TIMEOUT_TICKS, the mark
-//     blocks give up, raise WA_FLAG_OVERLAP_STARVED and wa_acs_sync fails loudly instead of the GPU hanging.
-#define WA_GEN_THREADS 1024
-#define WA_GEN_SWEEP_WAVE0 4
-#define WA_GEN_LDS_TAIL 64                     // bytes behind the walk block's LDS: go word, barrier counter, rank scalars
-#define WA_GEN_TIMEOUT_TICKS 20000000ll        // 0.2 s of the 100 MHz wall clock
-#ifdef WA_GEN_TIME   // diagnostic build (tools/gen_tail_time.py): wall-clock stamps of mark block 0, summed over the generations of a run
-#define WA_GT(i) do { if (b == 0 && tid == 0 && D.dbg) atomicAdd(&D.dbg[i], (unsigned long long)(wall_clock64() - gt0_)); } while (0)
-#else
-#define WA_GT(i) do { } while (0)
-#endif
-template <bool WARM, bool REJ>
-__global__ __launch_bounds__(WA_GEN_THREADS) void k_generation(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags,
-                                                               const float *src_base, float *dst_base, int32_t MB, int32_t split_log2,
-                                                               int32_t tail_off)
-{
-    extern __shared__ int32_t lds[];
-    const int32_t slot = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int32_t *tail = lds + (tail_off >> 2);     // [0] go, [1] barrier counter, [2] n_dep, [3] finite ants, [4..5] steps
-#ifdef WA_GEN_TIME
-    const long long gt0_ = wall_clock64();
-#endif
-    if (tid < WA_GEN_LDS_TAIL / 4) tail[tid] = 0;
-    __syncthreads();                           // the only s_barrier of the launch: every wavefront is still here
-    if (wave >= WA_GEN_SWEEP_WAVE0) {          // ---- sweep
-        const int32_t nw = (int32_t)(blockDim.x >> 6) - WA_GEN_SWEEP_WAVE0;
-        wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)6 * D.d.n, R.rho,
-                      b * nw + (wave - WA_GEN_SWEEP_WAVE0), (int32_t)gridDim.x * nw, 64, lane);
+    if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
+    // This block is a chain of dependent global loads beside a sweep that saturates the memory system (every level costs 2-3 us there):
+    // the ants' results are requested for ALL max_colony ants before the control block says how many there are (inside the allocation;
+    // entries beyond the colony are never looked at), and every ant's length goes to LDS with its key, so that the ranked ant's length is
+    // an LDS read: control block + results -> path words -> marks, three levels instead of five.
+    const int32_t cmax = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
+    for (int32_t a = tid; a < cmax; a += blockDim.x) {
+        const float La = antL[a];
+        const int32_t na = antLen[a];
+        s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
+        s_len[a] = na;
+    }
+    if (colony > D.max_colony || colony > WA_RANK_LDS) {
+        if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
         return;
     }
-    WaSlotCtl *ctl = &D.ctl[slot];
-    const int32_t colony = ctl->colony[gen & 1];
-    const bool bad = colony > D.max_colony || colony > WA_RANK_LDS;   // flagged by wa_rank_mark; nobody walks, nobody waits
-    if (wave == 0) {                           // ---- walk, then publish
-        if (b < colony && !bad) {
-            wa_walk_block<true, false, WARM, REJ>(D, R, hash_log2, gen, walk_flags, lds);
-            // the ant's cost, node count and path words are write-through stores (wa_st_pub): once they have completed (the wait
-            // a workgroup-scope release amounts to) the ticket may be seen -- no L2 write-back, no invalidate
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_fetch_add(&D.done[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int32_t myfin = 0;
+    unsigned long long mysteps = 0;
+    if (mb == 0)
+        for (int32_t a = tid; a < colony; a += blockDim.x) {
+            myfin += (__uint_as_float((uint32_t)(s_keys[a] >> 32)) != INFINITY) ? 1 : 0;
+            mysteps += (unsigned long long)(s_len[a] - 1);
         }
-        WA_GT(0);   // own ant done
-        if (b >= MB) return;
-        int32_t go = 1;
-        if (!bad) {                            // every ant of this search has a lower or equal dispatch index and a CU: they arrive
-            const long long t0 = wall_clock64();
-            // (relaxed polls: an acquire per poll would invalidate the XCD's L2 under the ants that are still walking; one fence below)
-            while (__hip_atomic_load(&D.done[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < colony) {
-                __builtin_amdgcn_s_sleep(32);
-                if (wall_clock64() - t0 > WA_GEN_TIMEOUT_TICKS) { go = 2; break; }
+    for (int32_t a = tid; a < colony; a += blockDim.x) {  // ascending (L, ant) by counting (:273-275, DEV tie rule)
+        const unsigned long long ka = s_keys[a];
+        int32_t r = 0;
+#pragma unroll 8
+        for (int32_t b = 0; b < colony; b++) r += s_keys[b] < ka ? 1 : 0;
+        s_perm[r] = a;
+        const int32_t o = r + 1;
+        const float La = __uint_as_float((uint32_t)(ka >> 32));
+        const bool ok = !(La == INFINITY || (float)o > lambda - 1);  // :200
+        if (ok) atomicMax(&s_ndep, o);
+        if (mb == 0) {  // publish for the apply pass
+            D.perm[(int64_t)slot * D.max_colony + r] = a;
+            D.depA[(int64_t)slot * D.max_colony + r] = ok ? (lambda - (float)o) * Q / La : 0.f;  // :211
+        }
+    }
+    if (mb == 0) {
+        for (int o = 32; o > 0; o >>= 1) { myfin += __shfl_down(myfin, o, 64); mysteps += __shfl_down(mysteps, o, 64); }
+        if ((tid & 63) == 0) { atomicAdd(&s_fin, myfin); atomicAdd(&s_steps, mysteps); }
+    }
+    __syncthreads();
+    const int32_t n_dep = s_ndep;
+    if (mb == 0) {  // ---- publish: iteration best -> global best (:263-264), trace, next parameters (:247-249)
+        float iterL = INFINITY;
+        int32_t iterAnt = -1;
+        if (colony > 0) { iterAnt = s_perm[0]; iterL = __uint_as_float((uint32_t)(s_keys[iterAnt] >> 32)); }  // rank 1 = first ant with the minimal L
+        float bestL = ctl->bestL;
+        uint32_t ver = ctl->best_ver;
+        int32_t blen = ctl->best_len;
+        bool changed = false;
+        if (iterAnt >= 0 && iterL < bestL) {
+            blen = s_len[iterAnt];
+            const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
+            int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
+            uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
+            int32_t *pos = D.bestpos + (int64_t)slot * D.d.n;
+            ver = ver + 1;
+            for (int32_t i = tid; i < blen; i += blockDim.x) {
+                int32_t w = srcp[i];
+                dstp[i] = w;
+                mark[w & WaNbT<NB>::IDM] = ver;
+                pos[w & WaNbT<NB>::IDM] = i;
+            }
+            bestL = iterL;
+            changed = true;
+        }
+        if (tid == 0) {
+            if (gen < D.trace_cap) {
+                int64_t t = (int64_t)slot * D.trace_cap + gen;
+                D.trBest[t] = bestL;
+                D.trIter[t] = iterL;
+                D.trColony[t] = colony;
+                D.trFinite[t] = s_fin;
+                D.trSteps[t] = (long long)s_steps;
+            }
+            // written in place, field by field (a local copy indexed by the generation's parity lives in scratch memory: the launch
+            // then needs a scratch set-up); nothing a sibling block reads during this launch changes: [gen&1] slots, start/end/stream
+            ctl->bestL = bestL;
+            ctl->best_len = blen;
+            ctl->best_ver = ver;
+            ctl->dep_lambda = lambda;
+            ctl->dep_Q = Q;
+            ctl->dep_bestL = bestL;
+            ctl->n_dep = n_dep;
+            ctl->gen = gen + 1;
+            if (changed) ctl->tabu_gen = gen;   // the replay-table rows of this generation rebuild the prefix-tabu bits
+            ctl->clean[(gen + 1) & 1] = ctl->clean[gen & 1] * R.rho;   // what one more evaporation makes of a never-deposited edge
+            wa_next_params(*ctl, R, (gen + 1) & 1);
+        }
+    }
+    // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
+    const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
+    if (o > n_dep) return;
+    const int32_t a = s_perm[o - 1];
+    const int32_t len = s_len[a];
+    const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
+    const WaMaskRef mask = wa_mask_of(D, slot);
+    float *ph = dst_base + (int64_t)slot * D.pher_stride;
+    const float clean_next = ctl->clean[gen & 1] * R.rho;   // == what block 0 publishes into clean[(gen+1)&1]
+    for (int32_t i = 1 + bx * blockDim.x + tid; i < len; i += (blockDim.x << split_log2)) {
+        int32_t w = path[i];
+        int32_t v = path[i - 1] & WaNbT<NB>::IDM;
+        int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
+        wa_mask_or(mask, e, bit);
+        if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
+            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
+            const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;
+            const uint32_t old = atomicExch(&stamp[v], target);
+            if (old == 0) {            // first deposit ever: v joins the dirty list, its record is written at the clean value
+                const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
+                D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
+                    const float st0 = ph[(int64_t)v * 6 + k];
+                    ph[(int64_t)v * 6 + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
+                }
+            } else if (old != target) {   // deposited before: apply the evaporations it has missed since
+#pragma unroll
+                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, R.rho);
             }
         }
-        WA_GT(1);   // every ant done
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the results are read with wa_ld_pub<true>: past every cache that could be stale)
-        if (go == 2 && lane == 0) atomicOr(&ctl->flags, WA_FLAG_OVERLAP_STARVED);
-        if (lane == 0) __hip_atomic_store(&tail[0], go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (go == 2) return;
-    } else {                                   // ---- wavefronts 1..3: the rest of a mark block
-        if (b >= MB) return;
-        int32_t go;
-        while ((go = __hip_atomic_load(&tail[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(8);
-        if (go == 2) return;
     }
-    // ---- rank + publish + mark, as mark block b of the search: 256 threads on the LDS the walk has left
-    const int32_t cmax = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
-    WaRankLds L;
-    L.keys = reinterpret_cast<unsigned long long *>(lds);
-    L.perm = lds + 2 * cmax;
-    L.len = lds + 3 * cmax;
-    L.ndep = tail + 2;
-    L.fin = tail + 3;
-    L.steps = reinterpret_cast<unsigned long long *>(tail + 4);
-    int32_t phase = 0;
-    wa_rank_mark<false, 6, true>(D, R, slot, gen, b, split_log2, dst_base, tid, 4 * 64, L, [&] {
-        phase += 4;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(&tail[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int32_t spins = 0; __hip_atomic_load(&tail[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase && spins < (1 << 24); spins++)
-            __builtin_amdgcn_s_sleep(1);   // (bounded: four wavefronts of one block, microseconds apart)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifdef WA_GEN_TIME
-        if (b == 0 && tid == 0 && D.dbg) atomicAdd(&D.dbg[2 + (phase >> 2) - 1], (unsigned long long)(wall_clock64() - gt0_));   // [2] results in LDS, [3] ranked
-#endif
-    });
-    WA_GT(4);   // block 0: published and marked
-#ifdef WA_GEN_TIME
-    if (b == 0 && tid == 0 && D.dbg) atomicAdd(&D.dbg[6], 1ull);
-#endif
 }
 
 // ------------------------------------------------------------------ evaporation (the HBM sweep)

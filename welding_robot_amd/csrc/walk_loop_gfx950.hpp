@@ -461,7 +461,7 @@
     "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
     "v_add_u32 v94, s46, v94\n"                                                                                   \
     "v_add_u32 v94, 0xffffff00, v94\n"                                                                            \
-    "global_store_dword v94, %[pbuf], %[path] sc1\n"                                                                  \
+    "global_store_dword v94, %[pbuf], %[path]\n"                                                                  \
     "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
     "s_cbranch_scc1 Lwa_out%=\n"                   /* ... and arrived with it (code 2) */                         \
     "s_mov_b32 %[code], 0\n"                                                                                      \
@@ -695,7 +695,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         // again after a boundary that was already handled is harmless.  (The watch looks once per step and never before the
         // first one -- s78 starts at -1 -- so at least one step was taken; the test on len keeps an empty pbuf from ever being
         // stored over a block that whoever brought the walk here had already written.)
-        if ((len & 63) == 0 && len != st.len) wa_st_pub(&path[(len - 64) + lane], pbuf);
+        if ((len & 63) == 0 && len != st.len) path[(len - 64) + lane] = pbuf;
         if (cur == end) exit_code = 2;                       // ... which had arrived (:182-186)
         else if (len >= limit) exit_code = 3;
         else st.reason = 4;
@@ -713,7 +713,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         st.done = true;
     }
     if (len & 63) {  // partial last block (entries [len & ~63, len))
-        if (lane < (len & 63)) wa_st_pub(&path[(len & ~63) + lane], pbuf);
+        if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;
     }
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
     st.pbuf = (len & 63) ? pbuf : 0; st.pbuf_valid = true;

@@ -22,8 +22,6 @@
 #include "traj_kernels.hpp"
 
 // ------------------------------------------------------------------ handles
-#include <atomic>
-static std::atomic<int> g_ctx_on_device[64];   // contexts of this process per device ordinal (k_generation wants to be alone)
 struct wa_ctx {
     int device;
     hipStream_t stream;    // every kernel of this context
@@ -72,8 +70,6 @@ struct wa_acs {
     std::vector<int> lazy_mode;         // per slot: init mode of the stored records (-1 unknown)
     std::vector<float> lazy_p0;
     int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks, lazy_blocks_env;
-    int64_t gens_total = 0, gens_overlapped = 0;   // generations enqueued / of those as k_generation -> k_apply_table (wa_acs_loop_info)
-    bool overlap = true, prof_as_is = false;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
     int32_t *d_hslot, *d_hlist, *d_hends;   // per search: the heuristic field it reads / the fields wa_acs_begin computes and their end points
@@ -160,11 +156,9 @@ int wa_ctx_create(int device_ordinal, wa_ctx **out)
         delete c;
         return WA_ERR_DEVICE;
     }
-    if (device_ordinal < 64) g_ctx_on_device[device_ordinal]++;
     *out = c;
     return WA_OK;
 }
-static bool wa_ctx_alone_on_device(const wa_ctx *c) { return c->device < 64 && g_ctx_on_device[c->device].load() == 1; }
 int wa_device_count(void)
 {
     int n = 0;
@@ -186,7 +180,6 @@ void wa_ctx_destroy(wa_ctx *c)
     if (!c) return;
     WaDevGuard dev_guard_(c);
     hipStreamDestroy(c->stream);
-    if (c->device < 64) g_ctx_on_device[c->device]--;
     delete c;
 }
 const char *wa_last_error(const wa_ctx *c) { return c ? c->err.c_str() : "no context"; }
