@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Does the evaporation sweep slow down when something else -- or nothing at all -- runs between two launches of it?
+k_evaporate (128^3, per-dispatch stamps) back to back, then with an idle gap on the same stream (torch.cuda._sleep), then with a kernel
+that streams through a third buffer of 48 / 192 MiB in between.  profiles/r03/fused_launch_anatomy.txt asks why the sweep lasts
+15.8-16.1 us inside the generation loop and 14.3-14.4 us back to back.
+
+    python tools/sweep_gap.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from welding_robot_amd import api, synth  # noqa: E402
+
+
+def main():
+    n = 128
+    torch.cuda.set_device(0)
+    ctx = api.Context(0)
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    s = api.AcsSolver(ctx, grid, n_slots=1, max_colony=8, path_capacity=1024)
+    s.init_pheromone(1.0)
+    ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", 0))
+    other = {mb: torch.zeros(mb * (1 << 20) // 4, dtype=torch.float32, device="cuda") for mb in (48, 192, 512)}
+    s.evaporate(0, 0.999, 8)
+    ctx.sync()
+
+    def run(label, between, reps=40):
+        s.profile(True, 1)
+        for _ in range(reps):
+            with torch.cuda.stream(ext):
+                between()
+            s.evaporate(0, 0.999, 1)
+        r = s.profile_read()["evaporate"]
+        print("%-58s k_evaporate %.2f us (x%d)" % (label, r["ms"] / r["launches"] * 1e3, r["launches"]))
+
+    run("back to back", lambda: None)
+    for us in (20, 170, 1000):
+        run("idle gap of ~%d us (torch.cuda._sleep)" % us, lambda us=us: torch.cuda._sleep(int(us * 100)))   # ~100 MHz ticks... see note
+    for mb in (48, 192, 512):
+        run("a %d MiB buffer scaled in place in between" % mb, lambda mb=mb: other[mb].mul_(1.0))
+    run("back to back again", lambda: None)
+
+
+if __name__ == "__main__":
+    main()
+
