@@ -43,6 +43,14 @@ def main():
         run("idle gap of ~%d us (torch.cuda._sleep)" % us, lambda us=us: torch.cuda._sleep(int(us * 100)))   # ~100 MHz ticks... see note
     for mb in (48, 192, 512):
         run("a %d MiB buffer scaled in place in between" % mb, lambda mb=mb: other[mb].mul_(1.0))
+    # the same kernel function on a tiny grid in between / another kernel of the same library on that tiny grid
+    f2, cx2, cy2, cz2, p2, w2 = synth.synth_grid(8, seed=1, occ_prob=0.0)
+    g2 = api.Grid.from_occupancy(ctx, f2, cx2, cy2, cz2, p2, w2)
+    t = api.AcsSolver(ctx, g2, n_slots=1, max_colony=8, path_capacity=64)
+    t.init_pheromone(1.0)
+    ctx.sync()
+    run("k_evaporate on an 8^3 grid in between (same function)", lambda: t.evaporate(0, 0.999, 1))
+    run("k_init_pheromone on an 8^3 grid in between", lambda: t.init_pheromone(1.0))
     run("back to back again", lambda: None)
 
 
