@@ -15,7 +15,7 @@ DIR = os.path.join(ROOT, "build", "spans")
 SPANS = [(1, 2, "record wait (2 compares + s_waitcnt vmcnt)"), (2, 3, "sign compare, info, two touch loads"), (3, 4, "masks (+ collision branch), v_cndmask"),
          (4, 5, "draw readlane, path words, the ten ordered adds"), (5, 6, "rnd, readlane, compare, s_and, rare-event branch"),
          (6, 7, "s_ff1, pick lane, path word readlane, insert"), (7, 8, "active mask, cur, first half of {record loads | probe}"),
-         (8, 9, "second half of {record loads | probe}"), (9, 10, "path word, m0, block / arrival events"), (10, 0, "back edge + touch address"),
+         (8, 9, "second half of {record loads | probe}"), (9, 10, "path word, m0, block / arrival events"), (10, 0, "back edge + touch address"), (0, 1, "touch address + s_waitcnt lgkmcnt (the probe's LDS round trip)"),
          (2, 2, "WHOLE STEP (point 2 to point 2)")]
 
 
@@ -36,12 +36,14 @@ if os.environ.get("WA_SPAN_CHILD"):
     from welding_robot_amd import api, synth
     gens = int(sys.argv[1])
     ctx = api.Context(0)
-    free, cx, cy, cz, prec, wall = synth.synth_grid(128, 2024, 0.10)
+    n = int(os.environ.get("WA_SPAN_GRID", "128"))   # 32 / 64: the whole field lives in the L2s
+    free, cx, cy, cz, prec, wall = synth.synth_grid(n, 2024, 0.10)
     grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
     s = api.AcsSolver(ctx, grid, 1, 256)
-    p = api.default_params(max_iteration=gens, predict=731.43, fixed_colony=256, rng_mode=api.RNG_DEV, seed=12345)
+    p = api.default_params(max_iteration=gens, predict=731.43 * n / 128, fixed_colony=256, rng_mode=api.RNG_DEV, seed=12345)
     s.profile(True, 1)
-    s.solve(p, 16513, 2097151)
+    ids = (16513, 2097151) if n == 128 else tuple(int(v) for v in grid.resolve(np.array([[1, 1, 1], [n - 1, n - 1, n - 1]], np.float32)))
+    s.solve(p, ids[0], ids[1])
     out = np.zeros(16, np.uint64)
     ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
     pr = s.profile_read()
@@ -50,6 +52,9 @@ if os.environ.get("WA_SPAN_CHILD"):
     os._exit(0)   # (the HIP runtime's static destructors occasionally throw at interpreter exit)
 gens = sys.argv[1] if len(sys.argv) > 1 else "10"
 tot = 0.0
+if os.environ.get("WA_SPAN_ONLY"):   # e.g. WA_SPAN_ONLY=1-2,2-2
+    want = {tuple(int(x) for x in t.split("-")) for t in os.environ["WA_SPAN_ONLY"].split(",")}
+    SPANS = [x for x in SPANS if (x[0], x[1]) in want]
 for a, b, name in SPANS:
     r = subprocess.run([sys.executable, os.path.abspath(__file__), gens], env=dict(os.environ, WELDACS_LIB=lib(a, b), WA_SPAN_CHILD="1"), capture_output=True, text=True)
     if r.returncode and len(r.stdout.split()) < 5:
