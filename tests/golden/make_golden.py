@@ -10,7 +10,7 @@ through it, for the HIP path.
     python3 tests/golden/make_golden.py            # regenerate everything (~2 min)
 
 Also copies the two binary STL *data* files the configs name (cubic.stl 684 B,
-simplified_piece.stl 299 KB) so that the GPU box -- which has no /root/reference -- can run
+simplified_piece.stl 299 KB; `origin` mode: origin_piece.stl 1.5 MB) so that the GPU box -- which has no /root/reference -- can run
 BASELINE configs C1/C2.
 """
 import os
@@ -155,6 +155,21 @@ def gen_nb26():
     print("synth64 nb26", a["best_L"], a["tr_steps"], a["tr_finite"])
 
 
+def gen_origin():
+    """The reference's largest mesh (files/origin_piece.stl, 29 888 triangles: the un-simplified work piece SURVEY 8(f) N1 quotes) voxelised
+    by the reference's creatGridMap at precision 0.0100, wall 4 (91 x 45 x 30 voxels: ~30 s of the reference's O(T N^3) loop)."""
+    f = "origin_piece.stl"
+    shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))
+    os.chmod(os.path.join(HERE, f), 0o644)
+    v = O.run_ref("voxelize", TMP + "/vo.waf", stl=os.path.join(HERE, f), p="0.0100", wall=4)
+    v = pack_free(v)
+    v["tris_head"] = v["tris"][:12 * 16].copy()
+    v["tris_sum"] = np.array([np.sum(v["tris"].astype(np.float64))])
+    del v["tris"]
+    print("reference voxelisation: %.2f s" % float(np.asarray(v.pop("t_voxelize", [0.0])).reshape(-1)[0]))
+    waf.save(HERE + "/vox_origin_p0100_w4.waf", v)
+
+
 def main():
     assert O.have_ref(), "build oracle/_ref first: make -C oracle"
     if len(sys.argv) > 1 and sys.argv[1] == "bspline":      # regenerate only the trajectory fixtures
@@ -169,6 +184,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "gridfile":
         gen_gridfile()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "origin":
+        gen_origin()
         return
     for f in ("cubic.stl", "simplified_piece.stl"):
         shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))

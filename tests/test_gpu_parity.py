@@ -55,7 +55,8 @@ def test_device_is_gfx950(ctx):
 # ------------------------------------------------------------------ voxelise + resolve (a3, a10)
 @pytest.mark.parametrize("tag,stl,p,wall", [("cubic_p0219_w8", "cubic.stl", "0.0219", 8),
                                             ("cubic_p0225_w8", "cubic.stl", "0.0225", 8),
-                                            ("piece_p0148_w4", "simplified_piece.stl", "0.0148", 4)])
+                                            ("piece_p0148_w4", "simplified_piece.stl", "0.0148", 4),
+                                            ("origin_p0100_w4", "origin_piece.stl", "0.0100", 4)])   # the reference's largest mesh: 29 888 triangles
 def test_voxelize_matches_reference(ctx, tag, stl, p, wall):
     g = _g("vox_%s.waf" % tag)
     tris = api.stl_read_file(os.path.join(G, stl))

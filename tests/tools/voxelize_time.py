@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api
 ctx = api.Context(0)
-tris = api.stl_read_file(os.path.join(ROOT, "tests", "golden", "simplified_piece.stl"))
+MESH = sys.argv[1] if len(sys.argv) > 1 else "simplified_piece.stl"   # or origin_piece.stl: the reference's largest mesh (29 888 triangles)
+tris = api.stl_read_file(os.path.join(ROOT, "tests", "golden", MESH))
 def timed(p, wall, dense):
     if dense:
         os.environ["WA_VOXELIZE_DENSE"] = "1"
@@ -29,6 +30,6 @@ for p, wall in [(0.0148, 4), (0.0065, 4), (0.0033, 4), (0.0021, 4), (0.0012, 4)]
         p, g.nx, g.ny, g.nz, g.n, len(tris), t * 1e3, td * 1e3, tests, tests / td / 1e9, same, g.n_free))
     if p == 0.0148:
         import oracle_lib as O
-        og = O.grid_from_mesh(O.stl_parse(open(os.path.join(ROOT, "tests", "golden", "simplified_piece.stl"), "rb").read()), p, wall)
+        og = O.grid_from_mesh(O.stl_parse(open(os.path.join(ROOT, "tests", "golden", MESH), "rb").read()), p, wall)
         print("   equals oracle:", bool(np.array_equal(g.occupancy(), og.free)))
     g.close()
