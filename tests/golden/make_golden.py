@@ -168,6 +168,13 @@ def gen_origin():
     del v["tris"]
     print("reference voxelisation: %.2f s" % float(np.asarray(v.pop("t_voxelize", [0.0])).reshape(-1)[0]))
     waf.save(HERE + "/vox_origin_p0100_w4.waf", v)
+    # ... and the reference's search across that grid, corner to corner (mesh -> grid -> ACS_Rank on the third data file)
+    kw = dict(stl=os.path.join(HERE, f), p="0.0100", wall=4, snode="0,0,0", enode="29,44,90", seed=2468, iters=100, predict="2.0", fixed=64)
+    a = O.run_ref("acs", TMP + "/ao.waf", **kw)
+    out = keep(a, ACS_KEYS)
+    out["args"] = np.frombuffer(repr(sorted((k, str(v) if k != "stl" else os.path.basename(v)) for k, v in kw.items())).encode(), np.uint8)
+    waf.save(HERE + "/acs_origin_fixed64.waf", out)
+    print("acs_origin_fixed64", a["best_L"], len(a["best_path"]))
 
 
 def main():

@@ -188,7 +188,7 @@ def _check_against_golden(ctx, tag, og=None, max_colony=None):
 
 
 @pytest.mark.parametrize("tag", ["acs_cubic_ka2_native", "acs_cubic_ka2_driven", "acs_cubic_predict5",
-                                 "acs_cubic_fixed16", "acs_cubic_seam", "acs_piece_adaptive", "acs_piece_fixed128"])
+                                 "acs_cubic_fixed16", "acs_cubic_seam", "acs_piece_adaptive", "acs_piece_fixed128", "acs_origin_fixed64"])
 def test_acs_ref_mode_equals_reference(ctx, tag):
     g = _check_against_golden(ctx, tag)
     if tag == "acs_cubic_seam":

@@ -164,7 +164,7 @@ def _run_acs_case(tag, grid=None):
 # probe taken after the solve -- hence rand_calls is compared before that probe is drawn.
 @pytest.mark.parametrize("tag", ["acs_cubic_ka2_native", "acs_cubic_ka2_driven", "acs_cubic_predict5",
                                  "acs_cubic_fixed16", "acs_cubic_seam", "acs_piece_adaptive",
-                                 "acs_piece_fixed128"])
+                                 "acs_piece_fixed128", "acs_origin_fixed64"])
 def test_acs_golden(tag):
     _run_acs_case(tag)
 
