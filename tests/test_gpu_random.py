@@ -81,3 +81,35 @@ def test_random_search_with_lazy_evaporation_equals_the_oracle(ctx, seed):
 def test_random_26_neighbour_search_equals_the_oracle(ctx, seed):
     og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
     run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par, nb=26)
+
+
+@pytest.mark.parametrize("seed,nb", [(s, 6) for s in range(300, 324)] + [(s, 26) for s in range(324, 336)])
+def test_random_search_in_ref_mode_equals_the_oracle(ctx, seed, nb):
+    """WA_RNG_REF: the reference's own glibc rand() stream and libstdc++ sort order, one ant after another (the oracle's REF mode is what
+    tests/test_oracle_golden.py holds against the reference itself).  The reference's default parameters: alpha 1, beta 0.6."""
+    og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
+    par["alpha"] = 1
+    iters = min(iters, 12)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max(bound, 1), neighbourhood=nb)
+    s.srand(rng_seed & 0x7FFFFFFF)
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_REF, **par)
+    s.init_pheromone(par["pheromone_0"])
+    s.solve(p, sid, eid)
+    a = O.Acs(og, nb=nb, pheromone_0=par["pheromone_0"])
+    rng = O.srand(rng_seed & 0x7FFFFFFF)
+    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.REF, rng=rng, alpha=par["alpha"], beta=par["beta"], rho=par["rho"],
+                 pheromone_0=par["pheromone_0"])
+    t = s.trace()
+    assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(t["colony"], tr["colony"]) and np.array_equal(t["finite"], tr["finite"])
+    assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))
+    cost, path, ch = s.result()
+    assert bits(cost) == bits(a.best_L)
+    if np.isfinite(cost):
+        assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
+    assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+    st = s.rand_state()   # the libc stream is where the oracle's is
+    assert [int(v) for v in st[:31]] == [int(v) for v in rng.r[:31]] and (int(st[34]), int(st[35])) == (int(rng.f), int(rng.b))   # 31 state words, front / back index
+    s.close()
+    dg.close()
