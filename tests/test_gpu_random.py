@@ -1,5 +1,8 @@
-"""Randomised differential test of the DEV search against the C oracle (bit-exact): random box grids, obstacles, end points, colony
-rules and parameters -- the combinations nobody wrote a case for.  Every case is a fixed seed, so a failure reproduces."""
+"""Randomised differential tests against the C oracle (bit-exact): searches on random box grids (obstacles, end points, colony rules,
+parameters), voxelisation of random meshes, seam ordering of random distance matrices -- the combinations nobody wrote a case for.
+Every case is a fixed seed, so a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,3 +116,70 @@ def test_random_search_in_ref_mode_equals_the_oracle(ctx, seed, nb):
     assert [int(v) for v in st[:31]] == [int(v) for v in rng.r[:31]] and (int(st[34]), int(st[35])) == (int(rng.f), int(rng.b))   # 31 state words, front / back index
     s.close()
     dg.close()
+
+
+# ------------------------------------------------------------------ voxelisation (a3 / N1)
+@pytest.mark.parametrize("seed", range(400, 424))
+def test_random_mesh_voxelisation_equals_the_oracle(ctx, seed):
+    rs = np.random.RandomState(seed)
+    nt = int(rs.randint(1, 120))
+    v = rs.uniform(-1, 1, (nt, 3, 3)).astype(np.float32) * np.float32(rs.choice([1.0, 0.05, 30.0]))
+    k = rs.rand(nt)
+    v[k < 0.3] = v[k < 0.3][:, :1] + rs.uniform(-0.06, 0.06, (int((k < 0.3).sum()), 3, 3)).astype(np.float32)   # small triangles
+    ax = int(rs.randint(0, 3))
+    flat = (k >= 0.3) & (k < 0.45)
+    v[flat, :, ax] = v[flat, :1, ax]                                                                              # axis-aligned ones
+    if nt > 4:
+        v[1] = v[1, 0]            # a point
+        v[2, 2] = v[2, 1]         # a segment
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = n / np.linalg.norm(n, axis=1, keepdims=True)
+    tris = np.zeros((nt, 12), np.float32)
+    tris[:, :3] = n
+    tris[:, 3:] = v.reshape(nt, 9)
+    ext = float((v.max(axis=(0, 1)) - v.min(axis=(0, 1))).max())
+    p = max(ext, 1e-3) / float(rs.randint(3, 40))
+    wall = int(rs.randint(0, 6))
+    og = O.grid_from_mesh(tris, p, wall)
+    a = api.Grid.from_mesh(ctx, tris, p, wall)
+    os.environ["WA_VOXELIZE_DENSE"] = "1"
+    try:
+        b = api.Grid.from_mesh(ctx, tris, p, wall)
+    finally:
+        del os.environ["WA_VOXELIZE_DENSE"]
+    assert (a.nx, a.ny, a.nz) == (og.nx, og.ny, og.nz) == (b.nx, b.ny, b.nz)
+    cx, cy, cz = a.coords()
+    assert np.array_equal(bits(cx), bits(og.cx)) and np.array_equal(bits(cy), bits(og.cy)) and np.array_equal(bits(cz), bits(og.cz))
+    assert np.array_equal(a.occupancy(), og.free) and np.array_equal(b.occupancy(), og.free)
+    a.close()
+    b.close()
+
+
+# ------------------------------------------------------------------ seam ordering (a13-a15)
+@pytest.mark.parametrize("seed", range(500, 524))
+def test_random_seam_ordering_equals_the_oracle(ctx, seed):
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(2, 90))
+    P = rs.uniform(0, 1, (n, 3)) * float(rs.choice([1.0, 100.0, 0.01]))
+    if n > 6 and rs.rand() < 0.5:
+        P[int(rs.randint(0, n))] = P[int(rs.randint(0, n))]            # two cities in one place: zero distance, ties
+    d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1) if rs.rand() < 0.5 else np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
+    cap = int(rs.choice([0, 0, 5, 17]))
+    sd, stream = int(rs.randint(1, 1 << 30)), int(rs.randint(0, 16))
+    o = O.gtsp_solve(d, mode=O.DEV, seed=sd, stream=stream, max_iterations=cap, want_pher=True)
+    for wave in ("1", "0"):
+        os.environ["WA_GTSP_WAVE"] = wave
+        try:
+            t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=sd, stream=stream, max_iterations=cap, want_pher=True)
+        finally:
+            del os.environ["WA_GTSP_WAVE"]
+        assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"], (n, wave)
+        assert np.array_equal(t["edges"][0], o["edges"]), (n, wave)
+        assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), (n, wave)
+    rng = O.srand(sd & 0x7FFFFFFF)                                      # the reference's own stream
+    st = np.array(list(rng.r) + [rng.f, rng.b], np.int32)
+    o = O.gtsp_solve(d, mode=O.REF, rng=rng, max_iterations=cap or 40)
+    t = api.gtsp_solve(ctx, d, mode=api.RNG_REF, rand_state=st, max_iterations=cap or 40)
+    assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
+    assert [int(v) for v in t["rand_state"][:31]] == list(rng.r)[:31]
