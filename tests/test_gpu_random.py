@@ -183,3 +183,40 @@ def test_random_seam_ordering_equals_the_oracle(ctx, seed):
     t = api.gtsp_solve(ctx, d, mode=api.RNG_REF, rand_state=st, max_iterations=cap or 40)
     assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
     assert [int(v) for v in t["rand_state"][:31]] == list(rng.r)[:31]
+
+
+# ------------------------------------------------------------------ B-spline smoothing (N3)
+def nbits(a):
+    a = np.ascontiguousarray(a, np.float32)
+    b = a.view(np.uint32).ravel().copy()
+    b[np.isnan(a).ravel()] = 0x7fc00000        # NaNs compare equal whatever their sign / payload
+    return b
+
+
+@pytest.mark.parametrize("seed", range(600, 632))
+def test_random_bspline_equals_the_oracle(ctx, seed):
+    rs = np.random.RandomState(seed)
+    dim, deg = int(rs.randint(1, 17)), int(rs.randint(0, 8))
+    ci, cf = int(rs.randint(0, deg + 1)), int(rs.randint(0, deg + 1))
+    n = int(rs.randint(max(2, deg), 3000))
+    tf = float(rs.choice([1.0, 150.0, 6000.0, 0.37]))
+    mid = (np.cumsum(rs.uniform(-0.01, 0.01, size=(n, dim)), axis=0) * float(rs.choice([1.0, 1000.0]))).astype(np.float32)
+    init = rs.uniform(-1, 1, size=(ci + 1, dim)).astype(np.float32)
+    fin = rs.uniform(-1, 1, size=(cf + 1, dim)).astype(np.float32)
+    ob = O.Bspline(dim, deg, ci, cf, n)
+    ob.set_param(init, fin, mid, tf)
+    b = api.Bspline(ctx, dim, deg, ci, cf, n)
+    b.set_param(init, fin, mid, tf)
+    knots, cps = b.arrays()
+    assert np.array_equal(nbits(knots), nbits(ob.knots)) and np.array_equal(nbits(cps), nbits(ob.cps))
+    count = int(rs.randint(1, 5000))
+    t0, dt = np.float32(-0.02 * tf), np.float32(1.05 * tf / count)
+    for der in sorted({0, min(1, deg), deg, deg + 1}):
+        got, ok = b.sample(t0, dt, count, der)
+        want, wok = ob.sample(t0, dt, count, der, prefill=0.0)
+        assert np.array_equal(ok, wok) and np.array_equal(nbits(got), nbits(want)), der
+    us = np.concatenate([rs.uniform(-0.5 * tf, 1.5 * tf, size=500), [0.0, tf, tf / 2]]).astype(np.float32)   # incl. both ends exactly
+    got, ok = b.eval(us)
+    want, wok = ob.eval(us, prefill=0.0)
+    assert np.array_equal(ok, wok) and np.array_equal(nbits(got), nbits(want))
+    b.close()
