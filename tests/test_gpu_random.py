@@ -220,3 +220,39 @@ def test_random_bspline_equals_the_oracle(ctx, seed):
     want, wok = ob.eval(us, prefill=0.0)
     assert np.array_equal(ok, wok) and np.array_equal(nbits(got), nbits(want))
     b.close()
+
+
+# ------------------------------------------------------------------ batches of searches in one solver (a11 / C4 / C5)
+@pytest.mark.parametrize("seed", range(700, 716))
+def test_random_batch_of_searches_equals_single_oracle_runs(ctx, seed):
+    """Several searches advance together in the slots of one solver (different end points, shared heuristic fields where they coincide,
+    their own DEV streams), twice in a row on the same solver; each must equal the oracle run on its own."""
+    rs = np.random.RandomState(seed)
+    nx, ny, nz = (int(rs.randint(4, 21)) for _ in range(3))
+    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.0, 0.15, 0.3])), seed=seed, p=float(rs.choice([1.0, 0.25])))
+    free = np.flatnonzero(og.free)
+    slots = int(rs.randint(2, 10))
+    lazy = bool(rs.rand() < 0.5)
+    ants = int(rs.randint(2, 40))
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    sb = api.AcsSolver(ctx, dg, n_slots=slots, max_colony=ants, lazy=lazy)
+    for rnd in range(2):
+        k = slots if rnd == 0 else int(rs.randint(1, slots + 1))         # the second batch may leave slots idle
+        ends = rs.choice(free, min(3, len(free)), replace=False)             # few distinct end points: heuristic fields are shared
+        starts = [int(v) for v in rs.choice(free, k)]
+        endl = [int(v) for v in rs.choice(ends, k)]
+        streams = [int(v) for v in rs.randint(0, 1000, k)]
+        iters, sd = int(rs.randint(1, 30)), int(rs.randint(1, 1 << 30))
+        p = api.default_params(max_iteration=iters, predict=float((nx + ny + nz) * og.precision), fixed_colony=ants, rng_mode=api.RNG_DEV, seed=sd)
+        sb.init_pheromone(1.0)   # (initFromGridMap; reset() also fills the out-of-bounds edges, which the pair-flow goldens cover)
+        sb.solve(p, starts, endl, streams=streams)
+        for q in range(k):
+            a = O.Acs(og)
+            a.solve(starts[q], endl[q], iters, float((nx + ny + nz) * og.precision), fixed_colony=ants, mode=O.DEV, seed=sd, stream=streams[q])
+            cost, path, _ = sb.result(q)
+            assert bits(cost) == bits(a.best_L), (rnd, q)
+            if np.isfinite(cost):
+                assert np.array_equal(path, a.best_path()[0])
+            assert np.array_equal(bits(sb.pheromone(q)), bits(a.pheromone())), (rnd, q)
+    sb.close()
+    dg.close()
