@@ -256,3 +256,16 @@ def test_random_batch_of_searches_equals_single_oracle_runs(ctx, seed):
             assert np.array_equal(bits(sb.pheromone(q)), bits(a.pheromone())), (rnd, q)
     sb.close()
     dg.close()
+
+
+@pytest.mark.parametrize("seed", range(800, 816))
+def test_random_medium_search_equals_the_oracle(ctx, seed):
+    """Corner-to-corner searches on 30..64-voxel grids: walks of a few hundred steps (several 64-word path blocks, table collisions),
+    enough generations for the best-path replay and -- from generation 16 on -- the rejoin watch; dense and lazy."""
+    rs = np.random.RandomState(seed)
+    nx, ny, nz = (int(rs.randint(30, 65)) for _ in range(3))
+    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.05, 0.1, 0.2])), seed=seed, p=1.0)
+    og.free[0] = og.free[-1] = 1
+    par = dict(alpha=1, beta=float(rs.choice([0.6, 1.0])), rho=float(rs.choice([0.8, 0.9])), pheromone_0=1.0)
+    run_variant(ctx, og, 0, nx * ny * nz - 1, int(rs.randint(20, 46)), float(nx + ny + nz), int(rs.randint(16, 65)), int(rs.randint(1, 1 << 30)),
+                int(rs.randint(0, 8)), par, lazy=bool(seed & 1))
