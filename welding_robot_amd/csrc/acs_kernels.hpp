@@ -55,8 +55,6 @@ struct WaAcsDev {
     uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
-    uint32_t *post_cnt;            // [slot][WA_POST_CNT] tickets of the merged post-walk launch (k_post_walk): [0] mark groups done, [1] sweep groups done,
-                                   // then one counter per group on a cache line of its own; zeroed by the walk launch of the generation
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
@@ -911,77 +909,14 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 // visited set = {best[0..i]}, i.e. neighbour nb is tabu iff it is marked and bestpos[nb] <= i (bits
 // precomputed by wa_best_prefix_tabu whenever the best path changes).
 // Output per node: thr[k] = admissible ? prob_sum_k : -inf (k = 0..5), total, edge taken to best[i+1].
-// Deferred stores of the merged post-walk launch (k_post_walk): its table / apply blocks run BESIDE the evaporation sweep, so they take the
-// evaporated value of an edge from the field the sweep reads (src * rho, the sweep's own multiplication) and keep what they have to store
-// until every sweep block has reported -- the sweep writes the whole field, their store must land after it.  WA_DEFER_MAX entries per
-// thread cover paths of 4 096 nodes; a thread that needs more waits for the sweep itself and stores directly from then on.
-#define WA_DEFER_MAX 4
-struct WaDefer {
-    const float *src;          // null: not deferred (the launch follows the sweep: read and write the current field)
-    float rho;
-    const uint32_t *sweep_cnt; // tickets of the sweep blocks ...
-    uint32_t sweep_target;     // ... and how many there are
-    int32_t n;
-    bool swept;
-    int64_t *e;                // this thread's column of the block's LDS stash: entry j at [j * blockDim.x]  (registers would be an indexed
-    float *p;                  // array, i.e. scratch memory -- and a launch with a scratch segment runs at half speed here: measured)
-};
-__device__ __forceinline__ bool wa_wait_tickets(const uint32_t *cnt, uint32_t target)
-{
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 20000000ll) return false;   // 0.2 s of the 100 MHz wall clock: the launch is being starved
-    }
-    return true;
-}
-// Thousands of blocks taking a ticket on ONE address serialise at ~50 ns each (4 096 sweep blocks: 200 us, measured): tickets are taken in
-// `groups` counters on cache lines of their own, and the block that completes a group takes one ticket on the top counter.
-#define WA_POST_CNT 2048                       // uint32 per slot: 2 top counters + 16-uint stride x (16 mark groups + 64 sweep groups) <= 1 282
-#define WA_POST_MARK_GROUPS 16
-#define WA_POST_SWEEP_GROUPS 64
-__device__ __forceinline__ void wa_group_ticket(uint32_t *top, uint32_t *sub, int32_t groups, int32_t idx, int32_t total)
-{
-    const int32_t g = idx % groups, size = total / groups + (g < total % groups ? 1 : 0);
-    const uint32_t old = __hip_atomic_fetch_add(&sub[g * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int32_t)old + 1 == size) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t wa_group_target(int32_t groups, int32_t total) { return (uint32_t)(total < groups ? total : groups); }
-
-__device__ __forceinline__ float wa_defer_load(const WaDefer &df, const float *pher, int64_t e)
-{
-    return df.src ? __fmul_rn(df.src[e], df.rho) : pher[e];   // (one rounding, no contraction with the deposits: the sweep's value)
-}
-__device__ __forceinline__ void wa_defer_store(WaDefer &df, float *pher, int64_t e, float p)
-{
-    if (!df.src || df.swept) { pher[e] = p; return; }
-    if (df.n == WA_DEFER_MAX) {   // (a path of more than 4 096 nodes)
-        wa_wait_tickets(df.sweep_cnt, df.sweep_target);
-        for (int j = 0; j < WA_DEFER_MAX; j++) pher[df.e[j * blockDim.x]] = df.p[j * blockDim.x];
-        df.n = 0;
-        df.swept = true;
-        pher[e] = p;
-        return;
-    }
-    df.e[df.n * blockDim.x] = e;
-    df.p[df.n * blockDim.x] = p;
-    df.n++;
-}
-__device__ __forceinline__ void wa_defer_flush(WaDefer &df, float *pher)
-{
-    if (!df.src || df.swept) return;
-    for (int j = 0; j < df.n; j++) pher[df.e[j * blockDim.x]] = df.p[j * blockDim.x];
-    df.n = 0;
-}
-
 template <int NB>
 __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
-                                              bool skip_best_src, float *s_dep, WaDefer *df = nullptr);
+                                              bool skip_best_src, float *s_dep);
 
 // apply_here: the row also APPLIES the pending ranked deposits (mask != 0) of its six edges -- same adds, same
 // ascending rank order as wa_apply_body -- writes them back, clears the masks, and evaluates on the new values.
 __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t row0, int32_t rows, bool apply_here,
-                                              const float *s_dep, int32_t w_first, int32_t w_first_next, WaDefer *df = nullptr)
+                                              const float *s_dep, int32_t w_first, int32_t w_first_next)
 {
     // w_first / w_first_next = bestpath[row0], bestpath[row0 + 1], loaded by the caller before the best length was
     // known (speculatively, inside the allocation) so that the row's record loads start one round trip earlier
@@ -1018,7 +953,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
         const int32_t v = wv & (int32_t)WA_ID_MASK;
         // all record loads of the row are independent of each other
         const int64_t e = (int64_t)v * 6 + kk;
-        float p = df ? wa_defer_load(*df, pher, e) : pher[e];
+        float p = pher[e];
         const float h = heur[e];
         if (stamp) {
             const uint32_t stv = stamp[v];
@@ -1047,7 +982,7 @@ __device__ __forceinline__ void wa_table_rows(const WaAcsDev &D, const WaRun &R,
                     m &= m - 1;
                     p += s_dep[b] + bonus;
                 }
-                if (df) wa_defer_store(*df, pher, e, p); else pher[e] = p;
+                pher[e] = p;
                 wa_mask_clear(mask, e);
             }
             // in bounds and free (:148), and not on the prefix best[0..i] (:145-146)
@@ -1118,8 +1053,6 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
-    if (blockIdx.x == gridDim.x - 1)   // the tickets of this generation's k_post_walk (the last walk block: usually not an ant that sets the launch time)
-        for (int32_t i = threadIdx.x; i < 16 * (1 + WA_POST_MARK_GROUPS + WA_POST_SWEEP_GROUPS); i += 64) D.post_cnt[(int64_t)WA_POST_CNT * slot + i] = 0;
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0, rs_unused = 0;
@@ -1425,15 +1358,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 // thread, grid-stride over E blocks.  One definition for k_evaporate and the fused k_evap_rank_mark.
 typedef float wa_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p) { return *p; }
-// WT: write-through (`sc1`) -- the merged post-walk launch stores deposits over swept values from other blocks of the SAME launch, so
-// a swept line must not stay dirty in the sweeping XCD's L2 (measured: the sweep is as fast either way)
-template <bool WT>
-__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v)
-{
-    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else *p = v;
-}
-template <bool WT = false>
+__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v) { *p = v; }
 __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
 {
     const wa_v4f *s4 = reinterpret_cast<const wa_v4f *>(src);
@@ -1444,18 +1369,16 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
     for (; i + 3 * gsz < n4; i += 4 * gsz) {
         wa_v4f a = wa_sweep_ld(s4 + i), b = wa_sweep_ld(s4 + i + gsz), c = wa_sweep_ld(s4 + i + 2 * gsz), d = wa_sweep_ld(s4 + i + 3 * gsz);
         a *= rho; b *= rho; c *= rho; d *= rho;
-        wa_sweep_st<WT>(d4 + i, a); wa_sweep_st<WT>(d4 + i + gsz, b); wa_sweep_st<WT>(d4 + i + 2 * gsz, c); wa_sweep_st<WT>(d4 + i + 3 * gsz, d);
+        wa_sweep_st(d4 + i, a); wa_sweep_st(d4 + i + gsz, b); wa_sweep_st(d4 + i + 2 * gsz, c); wa_sweep_st(d4 + i + 3 * gsz, d);
     }
     for (; i < n4; i += gsz) {
         wa_v4f a = wa_sweep_ld(s4 + i);
         a *= rho;
-        wa_sweep_st<WT>(d4 + i, a);
+        wa_sweep_st(d4 + i, a);
     }
     // tail (n_floats is even; at most 2 floats)
     const int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + threadIdx.x;
-    if (t < n_floats) {
-        if (WT) __hip_atomic_store(&dst[t], src[t] * rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else dst[t] = src[t] * rho;
-    }
+    if (t < n_floats) dst[t] = src[t] * rho;
 }
 
 // ------------------------------------------------------------------ fused post-walk launch (DEV mode)
@@ -1469,22 +1392,53 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
 // split_log2: mark blocks per depositing rank = 1 << this (C3, 500 generations: 8 blocks per rank 21.6 k gen/s, 4 22.1 k, 2 21.9 k;
 // C5 with 224 searches per launch: 4 blocks 0.636 s, 2 0.622 s, 1 0.623 s) -- the host passes 2 or 1
-// ---- rank + publish + mark as mark block `mb` of a launch (block = 256 threads): the post-walk launches' first role
 template <bool SPARSE, int NB>
-__device__ __forceinline__ void wa_rank_mark_role(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t gen, int32_t mb, int32_t split_log2, float *dst_base)
+__global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
+                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period)
 {
-    const int32_t tid = threadIdx.x;
+    const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
+    // their latency-bound work hides under the sweep blocks that follow
+    if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
+        if (!SPARSE) {
+            wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
+                          (int32_t)blockIdx.x - MB, E);
+        } else {
+            // lazy evaporation, background pass: every lazy_period-th entry of the dirty list (phase = generation) is brought
+            // current in place, so no record has more than ~lazy_period multiplications pending (whoever reads a record applies
+            // the pending ones exactly, one rounding each: the period only trades this pass against those catch-ups; the host
+            // passes 16 for a few searches per launch and 64 for 64 and more -- C5, 224 searches: 16 0.618 s, 32 0.583, 64 0.570,
+            // 256 0.563; the 32-search pair planning of bench.py: 325 k / 320 k / 303 k pair-generations/s with 16 / 32 / 64)
+            // A record is claimed by exchanging its stamp (the mark blocks of this launch claim the same way when a
+            // voxel receives a deposit), so exactly one thread applies the pending multiplications.
+            float *ph = dst_base + (int64_t)slot * D.pher_stride;
+            const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
+            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
+            const int32_t n0 = D.dcount[slot * 2];
+            const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)gen;
+            const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
+            const float rho = R.rho;
+            const int64_t first = (int64_t)(evap_now % (uint32_t)lazy_period);
+            for (int64_t q = first + (int64_t)lazy_period * ((int64_t)((int32_t)blockIdx.x - MB) * blockDim.x + tid); q < n0;
+                 q += (int64_t)lazy_period * E * blockDim.x) {
+                const int32_t v = list[q];
+                const uint32_t old = atomicExch(&stamp[v], target);
+                if (old == target) continue;
+#pragma unroll
+                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho);
+            }
+        }
+        return;
+    }
+    // ---- rank + mark
+    const int32_t mb = (int32_t)blockIdx.x;  // 0..511: (bx = mb & 7, rank bit = mb >> 3)
     WaSlotCtl *ctl = &D.ctl[slot];
     const int32_t colony = ctl->colony[gen & 1];
     const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
     const float *antL = D.antL + (int64_t)slot * D.max_colony;
     const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
-    // the ranking's LDS arrays are sized by the solver's colony (16 B per ant, dynamic): a static 2 048-ant allocation is 32 KB for EVERY
-    // block of the launch, the sweep blocks included -- four resident blocks per CU, of which the waiting blocks of k_post_walk hold half
-    extern __shared__ unsigned long long s_rank_lds[];
-    const int32_t cap = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
-    unsigned long long *s_keys = s_rank_lds;
-    int32_t *s_perm = reinterpret_cast<int32_t *>(s_rank_lds + cap), *s_len = s_perm + cap;
+    __shared__ unsigned long long s_keys[WA_RANK_LDS];
+    __shared__ int32_t s_perm[WA_RANK_LDS], s_len[WA_RANK_LDS];
     __shared__ int32_t s_ndep, s_fin;
     __shared__ unsigned long long s_steps;
     if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
@@ -1614,148 +1568,6 @@ __device__ __forceinline__ void wa_rank_mark_role(const WaAcsDev &D, const WaRun
     }
 }
 
-template <bool SPARSE, int NB>
-__global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period)
-{
-    const int32_t slot = blockIdx.y, tid = threadIdx.x;
-    // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
-    // their latency-bound work hides under the sweep blocks that follow
-    if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
-        if (!SPARSE) {
-            wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
-                          (int32_t)blockIdx.x - MB, E);
-        } else {
-            // lazy evaporation, background pass: every lazy_period-th entry of the dirty list (phase = generation) is brought
-            // current in place, so no record has more than ~lazy_period multiplications pending (whoever reads a record applies
-            // the pending ones exactly, one rounding each: the period only trades this pass against those catch-ups; the host
-            // passes 16 for a few searches per launch and 64 for 64 and more -- C5, 224 searches: 16 0.618 s, 32 0.583, 64 0.570,
-            // 256 0.563; the 32-search pair planning of bench.py: 325 k / 320 k / 303 k pair-generations/s with 16 / 32 / 64)
-            // A record is claimed by exchanging its stamp (the mark blocks of this launch claim the same way when a
-            // voxel receives a deposit), so exactly one thread applies the pending multiplications.
-            float *ph = dst_base + (int64_t)slot * D.pher_stride;
-            const int32_t *list = D.dirty_list + (int64_t)slot * D.d.n;
-            uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
-            const int32_t n0 = D.dcount[slot * 2];
-            const uint32_t evap_now = D.ctl[slot].evap_base + (uint32_t)gen;
-            const uint32_t target = evap_now + 2u;   // stamp of "current after this generation's evaporation"
-            const float rho = R.rho;
-            const int64_t first = (int64_t)(evap_now % (uint32_t)lazy_period);
-            for (int64_t q = first + (int64_t)lazy_period * ((int64_t)((int32_t)blockIdx.x - MB) * blockDim.x + tid); q < n0;
-                 q += (int64_t)lazy_period * E * blockDim.x) {
-                const int32_t v = list[q];
-                const uint32_t old = atomicExch(&stamp[v], target);
-                if (old == target) continue;
-#pragma unroll
-                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho);
-            }
-        }
-        return;
-    }
-    // ---- rank + mark
-    wa_rank_mark_role<SPARSE, NB>(D, R, slot, gen, (int32_t)blockIdx.x, split_log2, dst_base);   // mb: (bx = mb & 3, rank bit = mb >> 2)
-}
-
-// ------------------------------------------------------------------ merged post-walk launch (one or a few dense 6-neighbour DEV searches)
-// sweep + rank + mark + apply + replay table in ONE launch: the launch that used to follow (k_apply_table) costs ~6.5 us between its
-// events even when every block returns at once, and its ~4 us of work is a chain of dependent loads that can run under the sweep.
-// Roles by block index: [0, MB) rank + mark as in k_evap_rank_mark; then `pre` sweep blocks; then TB table + AB apply blocks; then the
-// rest of the E sweep blocks.
-//   * a mark block ends with a release fence and a ticket (post_cnt[0]); the table / apply blocks wait for all MB tickets (thread 0
-//     polls, relaxed; the mark blocks have lower block indices, so they are resident or done), then an acquire fence.  Fences are cheap
-//     HERE: nothing latency-bound shares the XCD, and the sweep's stores are write-through, so there is little to write back.
-//   * the table / apply blocks do not read the swept field: the evaporated value of an edge is src * rho, the sweep's own multiplication
-//     (wa_defer_load), so their whole chain runs beside the sweep; only their STORES must land after the sweep's (it writes every
-//     element): they are kept (WaDefer) until all E sweep blocks have reported (post_cnt[1]; a sweep block's write-through stores have
-//     completed when it takes its ticket), then written.  The replay table itself (rtab) is nobody else's and is written at once.
-//   * waits are bounded (0.2 s): a launch starved by foreign work raises WA_FLAG_LAUNCH_STARVED and wa_acs_sync fails.
-// post_cnt is zeroed by the walk launch of the same generation.
-#ifdef WA_POST_TIME   // diagnostic build (tools/post_walk_time.py): wall-clock stamps per role, max over the blocks of ONE launch
-#define WA_PT_START() do { if (threadIdx.x == 0 && D.dbg && (blockIdx.x & 63) == 0) atomicMax(&D.dbg[0], ~(unsigned long long)wall_clock64()); } while (0)   /* ~dbg[0] = earliest start (of every 64th block: an atomic per block on one address would be the measurement) */
-#define WA_PT(i) do { if (threadIdx.x == 0 && D.dbg && ((i) != 3 || (blockIdx.x & 31) == 31 || blockIdx.x + 1 == gridDim.x)) atomicMax(&D.dbg[i], (unsigned long long)wall_clock64()); } while (0)
-#else
-#define WA_PT_START() do { } while (0)
-#define WA_PT(i) do { } while (0)
-#endif
-__global__ __launch_bounds__(256) void k_post_walk(WaAcsDev D, WaRun R, const float *src_base, float *dst_base, int32_t E, int32_t gen,
-                                                   int32_t MB, int32_t split_log2, int32_t TB, int32_t AB, int32_t pre)
-{
-    __shared__ float s_dep[64];
-    __shared__ int32_t s_ok;
-    __shared__ int64_t s_de[WA_DEFER_MAX * 256];
-    __shared__ float s_dp[WA_DEFER_MAX * 256];
-    const int32_t slot = blockIdx.y, tid = threadIdx.x;
-    uint32_t *cnt = D.post_cnt + (int64_t)WA_POST_CNT * slot;
-    uint32_t *mark_sub = cnt + 16, *sweep_sub = cnt + 16 * (1 + WA_POST_MARK_GROUPS);
-    int32_t bx = (int32_t)blockIdx.x;
-    WA_PT_START();
-    if (bx < MB) {   // ---- rank + publish + mark
-        wa_rank_mark_role<false, 6>(D, R, slot, gen, bx, split_log2, dst_base);
-        WA_PT(1);   // marks written
-        __threadfence();
-        __syncthreads();
-        WA_PT(2);   // ... and released
-        if (tid == 0) wa_group_ticket(&cnt[0], mark_sub, WA_POST_MARK_GROUPS, bx, MB);
-        return;
-    }
-    bx -= MB;
-    const int32_t TA = TB + AB;
-    if (bx < pre || bx >= pre + TA) {   // ---- sweep, write-through
-        const int32_t ebx = bx < pre ? bx : bx - TA;
-        wa_sweep_body<true>(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)6 * D.d.n, R.rho, ebx, E);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        WA_PT(3);   // sweep block done
-        if (tid == 0) wa_group_ticket(&cnt[1], sweep_sub, WA_POST_SWEEP_GROUPS, ebx, E);
-        return;
-    }
-    bx -= pre;
-    // ---- table rows / apply, beside the sweep
-    if (tid == 0) s_ok = wa_wait_tickets(&cnt[0], wa_group_target(WA_POST_MARK_GROUPS, MB)) ? 1 : 0;
-    __syncthreads();
-    if (!s_ok) {
-        if (tid == 0) atomicOr(&D.ctl[slot].flags, WA_FLAG_LAUNCH_STARVED);
-        return;
-    }
-    WA_PT(4);   // marks seen
-    __threadfence();
-    WA_PT(5);   // acquired
-    WaDefer df;
-    df.src = src_base + (int64_t)slot * D.pher_stride;
-    df.rho = R.rho;
-    df.sweep_cnt = &cnt[1];
-    df.sweep_target = wa_group_target(WA_POST_SWEEP_GROUPS, E);
-    df.n = 0;
-    df.swept = false;
-    df.e = s_de + tid;
-    df.p = s_dp + tid;
-    float *pher = dst_base + (int64_t)slot * D.pher_stride;
-    if (bx < TB) {
-        const int32_t row0 = (bx * (int32_t)blockDim.x + tid) >> 4;
-        const float dep_mine = (tid < 64 && tid < D.max_colony) ? D.depA[(int64_t)slot * D.max_colony + tid] : 0.f;
-        const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
-        const int32_t w0 = row0 < D.path_cap ? bpath[row0] : 0, w1 = row0 + 1 < D.path_cap ? bpath[row0 + 1] : 0;
-        const int32_t n_dep = D.ctl[slot].n_dep;
-        if (tid < 64) s_dep[tid] = tid < n_dep ? dep_mine : 0.f;
-        __syncthreads();
-        wa_table_rows(D, R, slot, row0, (TB * (int32_t)blockDim.x) >> 4, true, s_dep, w0, w1, &df);
-    } else {
-        const int32_t ab = bx - TB;
-        wa_apply_body<6>(D, slot, 0, ab >> split_log2, ab & ((1 << split_log2) - 1), 1 << split_log2, true, s_dep, &df);
-    }
-    __syncthreads();
-    WA_PT(6);   // table / apply computed
-    if (tid == 0) s_ok = wa_wait_tickets(&cnt[1], wa_group_target(WA_POST_SWEEP_GROUPS, E)) ? 1 : 0;
-    __syncthreads();
-    if (!s_ok) {
-        if (tid == 0) atomicOr(&D.ctl[slot].flags, WA_FLAG_LAUNCH_STARVED);
-        return;
-    }
-    WA_PT(7);   // sweep seen
-    wa_defer_flush(df, pher);
-    WA_PT(8);
-}
-
 // ------------------------------------------------------------------ evaporation (the HBM sweep)
 // :268-272 -- every edge of every voxel, occupied voxels and out-of-bounds edges included:
 // dst = src * rho over 6N floats, 48 B of traffic per voxel (24 read + 24 written).  The
@@ -1796,7 +1608,7 @@ __global__ __launch_bounds__(256) void k_deposit_mark(WaAcsDev D, int32_t base)
 // leave a best-path node belong to the replay-table rows of the same launch (k_apply_table).
 template <int NB>
 __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, int32_t base, int32_t bit, int32_t bx, int32_t nbx,
-                                              bool skip_best_src, float *s_dep, WaDefer *df)
+                                              bool skip_best_src, float *s_dep)
 {
     // The kernel is a chain of dependent global loads (control block -> rank -> ant -> path word -> edge record),
     // so loads are issued as early as their addresses are known, speculatively where a bound is not yet known
@@ -1828,7 +1640,7 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
         // level 3: four independent loads
         const uint32_t mv = mark[v], mw = mark[w & WaNbT<NB>::IDM];
         unsigned long long m = wa_mask_get(mask, e);
-        float p = df ? wa_defer_load(*df, pher, e) : pher[e];
+        float p = pher[e];
         const bool v_best = mv == ver;
         if (skip_best_src && v_best) continue;
         if (m == 0 || (__ffsll((long long)m) - 1) != bit) continue;  // not the owner
@@ -1839,7 +1651,7 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
             m &= m - 1;
             p += s_dep[b] + bonus;  // :210-211
         }
-        if (df) wa_defer_store(*df, pher, e, p); else pher[e] = p;
+        pher[e] = p;
         wa_mask_clear(mask, e);
     }
 }

@@ -18,7 +18,7 @@
 #define WA_HASH_SENTINEL (-2)   // the entry behind the table (see wa_tabu_clear): never empty, never a voxel id
 #define WA_MAX_TRACKED_ERR 1
 
-enum { WA_FLAG_PATH_OVERFLOW = 1, WA_FLAG_COLONY_OVERFLOW = 2, WA_FLAG_BITMAP_USED = 4, WA_FLAG_LAUNCH_STARVED = 8 };
+enum { WA_FLAG_PATH_OVERFLOW = 1, WA_FLAG_COLONY_OVERFLOW = 2, WA_FLAG_BITMAP_USED = 4 };
 
 struct WaDims {
     int32_t nx, ny, nz;
