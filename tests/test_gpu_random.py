@@ -269,3 +269,30 @@ def test_random_medium_search_equals_the_oracle(ctx, seed):
     par = dict(alpha=1, beta=float(rs.choice([0.6, 1.0])), rho=float(rs.choice([0.8, 0.9])), pheromone_0=1.0)
     run_variant(ctx, og, 0, nx * ny * nz - 1, int(rs.randint(20, 46)), float(nx + ny + nz), int(rs.randint(16, 65)), int(rs.randint(1, 1 << 30)),
                 int(rs.randint(0, 8)), par, lazy=bool(seed & 1))
+
+
+# ------------------------------------------------------------------ the same random searches down the other code paths
+KNOBS = [dict(WA_WALK_ASM="0"),                         # the compiler-scheduled loop instead of the hand-scheduled one
+         dict(WA_WALK_WARM="0"),                        # no touch loads (the saturated-launch variant of the loop)
+         dict(WA_HASH_LOG2="6"),                        # a 64-entry tabu table: probe chains, spill to the global bitmap
+         dict(WA_HASH_LOG2="8", WA_WALK_WARM="0"),
+         dict(WA_REENTRY="0"),                          # no rejoin watch
+         dict(WA_REENTRY_STABLE="1"),                   # ... armed after one stable generation
+         dict(WA_EVAP_BLOCKS="7"), dict(WA_LAZY_BLOCKS="3")]   # odd sweep / background-pass grids
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_random_searches_down_the_other_code_paths(ctx, knobs, monkeypatch):
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)   # read by wa_acs_create
+    for seed in list(range(0, 96, 8)) + [801, 806, 811]:
+        if seed < 800:
+            og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
+            run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par, lazy=bool(seed & 8))
+        else:
+            rs = np.random.RandomState(seed)
+            nx, ny, nz = (int(rs.randint(30, 65)) for _ in range(3))
+            og = box_grid(nx, ny, nz, occ_prob=0.1, seed=seed, p=1.0)
+            og.free[0] = og.free[-1] = 1
+            run_variant(ctx, og, 0, nx * ny * nz - 1, 24, float(nx + ny + nz), 32, seed, 1, dict(alpha=1, beta=0.6, rho=0.8, pheromone_0=1.0),
+                        lazy=bool(seed & 1))
