@@ -1,6 +1,6 @@
-"""Randomised differential tests against the C oracle (bit-exact): searches on random box grids (obstacles, end points, colony rules,
-parameters), voxelisation of random meshes, seam ordering of random distance matrices -- the combinations nobody wrote a case for.
-Every case is a fixed seed, so a failure reproduces."""
+"""Randomised differential sweep: seeded random small problems (grid shape, obstacle density, voxel pitch, alpha, beta,
+rho, pheromone_0, colony rule, generations, hash size) solved by the dense solver, the lazily evaporating solver and
+the 26-neighbour solver, each against the C oracle -- traces, best path and the full pheromone field bit for bit."""
 import os
 
 import numpy as np
@@ -8,9 +8,14 @@ import pytest
 
 import oracle_lib as O
 from welding_robot_amd import api
-from test_gpu_edges import bits, box_grid
 
 pytestmark = pytest.mark.gpu
+CHUNKS = int(os.environ.get("WA_RANDOM_CHUNKS", "16"))   # 10 problems each; raise it for a soak run
+CHUNKS4 = max(4, CHUNKS // 4)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
 @pytest.fixture(scope="module")
@@ -20,279 +25,210 @@ def ctx():
     c.close()
 
 
-def draw_case(seed):
-    rs = np.random.RandomState(1000 + seed)
-    nx, ny, nz = (int(rs.randint(3, 25)) for _ in range(3))
-    p = float(rs.choice([1.0, 0.5, 0.013]))
-    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.0, 0.1, 0.2, 0.35])), seed=seed, p=p)
-    free = np.flatnonzero(og.free)
-    if len(free) < 2:
-        og = box_grid(nx, ny, nz, 0.0, seed, p)
-        free = np.flatnonzero(og.free)
-    sid, eid = (int(v) for v in rs.choice(free, 2, replace=False))
-    par = dict(alpha=int(rs.choice([1, 1, 1, 2])), beta=float(rs.choice([0.6, 1.0, 2.5])), rho=float(rs.choice([0.5, 0.8, 0.95])),
-               pheromone_0=float(rs.choice([1.0, 0.3])))
-    diam = (nx + ny + nz) * p
-    if rs.rand() < 0.5:
-        fixed, predict = int(rs.randint(1, 97)), diam
-    else:   # adaptive colony (:247): 0.35 * min(best, predict) / precision ants, at least a few
-        fixed, predict = 0, diam * float(rs.uniform(0.4, 3.0))
-        if int(0.35 * predict / p) < 1:
-            fixed = 3
-    iters = int(rs.randint(1, 41))
-    return og, sid, eid, iters, predict, fixed, int(rs.randint(1, 1 << 30)), int(rs.randint(0, 8)), par
+def random_case(rs):
+    nx, ny, nz = (int(v) for v in rs.randint(1, 14, size=3))
+    pitch = float(np.float32(rs.choice([1.0, 0.25, 0.0219, 3.0])))
+    free = (rs.uniform(size=nx * ny * nz) >= rs.choice([0.0, 0.1, 0.3])).astype(np.uint8)
+    fr = np.flatnonzero(free)
+    if len(fr) < 2:
+        free[:] = 1
+        fr = np.arange(len(free))
+    sid, eid = (int(v) for v in rs.choice(fr, size=2, replace=len(fr) < 2))
+    og = O.Grid(np.arange(nx, dtype=np.float32) * np.float32(pitch), np.arange(ny, dtype=np.float32) * np.float32(pitch),
+                np.arange(nz, dtype=np.float32) * np.float32(pitch), free, pitch, 0)
+    par = dict(alpha=int(rs.choice([1, 1, 2, 0, 3])), beta=float(np.float32(rs.choice([0.6, 0.0, 1.5, 0.95]))),
+               rho=float(np.float32(rs.choice([0.8, 0.5, 0.99, 1.0]))), pheromone_0=float(np.float32(rs.choice([1.0, 0.3, 7.0]))))
+    fixed = int(rs.choice([0, 0, 5, 12, 40]))
+    predict = float(np.float32(rs.uniform(2, 30) * pitch))
+    if fixed == 0 and int(0.35 * predict / pitch) < 1:
+        fixed = 3
+    iters = int(rs.choice([1, 3, 10, 25, 60]))
+    return og, sid, eid, par, fixed, predict, iters, int(rs.randint(0, 1 << 30)), int(rs.randint(0, 50))
 
 
-def run_variant(ctx, og, sid, eid, iters, predict, fixed, seed, stream, par, nb=6, lazy=False):
+def check(ctx, og, sid, eid, par, fixed, predict, iters, seed, stream, nb, lazy):
     dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
     bound = fixed if fixed else int(0.35 * predict / float(og.precision))
-    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max(bound, 1), neighbourhood=nb, lazy=lazy)
+    s = api.AcsSolver(ctx, dg, 1, max(bound, 1), neighbourhood=nb, lazy=lazy)
     p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_DEV, seed=seed, **par)
     s.init_pheromone(par["pheromone_0"])
     s.solve(p, sid, eid, streams=[stream])
-    a = O.Acs(og, nb=nb, pheromone_0=par["pheromone_0"])
-    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream, alpha=par["alpha"], beta=par["beta"],
-                 rho=par["rho"], pheromone_0=par["pheromone_0"])
+    a = O.Acs(og, pheromone_0=par["pheromone_0"], nb=nb)
+    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.DEV, seed=seed, stream=stream, **par)
     t = s.trace()
-    assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(t["colony"], tr["colony"]) and np.array_equal(t["finite"], tr["finite"])
-    assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))
-    cost, path, ch = s.result()
-    assert bits(cost) == bits(a.best_L)
-    if np.isfinite(cost):
-        assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
-    assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))          # the whole field
-    L, lens = s.ants()
-    olen, oL = a.last_ants()
-    assert np.array_equal(bits(L), bits(oL)) and np.array_equal(lens, olen)   # every ant of the last generation
-    s.close()
-    dg.close()
-
-
-@pytest.mark.parametrize("seed", range(96))
-def test_random_search_equals_the_oracle(ctx, seed):
-    og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
-    run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par)
-
-
-@pytest.mark.parametrize("seed", range(100, 132))
-def test_random_search_with_lazy_evaporation_equals_the_oracle(ctx, seed):
-    og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
-    run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par, lazy=True)
-
-
-@pytest.mark.parametrize("seed", range(200, 232))
-def test_random_26_neighbour_search_equals_the_oracle(ctx, seed):
-    og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
-    run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par, nb=26)
-
-
-@pytest.mark.parametrize("seed,nb", [(s, 6) for s in range(300, 324)] + [(s, 26) for s in range(324, 336)])
-def test_random_search_in_ref_mode_equals_the_oracle(ctx, seed, nb):
-    """WA_RNG_REF: the reference's own glibc rand() stream and libstdc++ sort order, one ant after another (the oracle's REF mode is what
-    tests/test_oracle_golden.py holds against the reference itself).  The reference's default parameters: alpha 1, beta 0.6."""
-    og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
-    par["alpha"] = 1
-    iters = min(iters, 12)
-    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
-    bound = fixed if fixed else int(0.35 * predict / float(og.precision))
-    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=max(bound, 1), neighbourhood=nb)
-    s.srand(rng_seed & 0x7FFFFFFF)
-    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_REF, **par)
-    s.init_pheromone(par["pheromone_0"])
-    s.solve(p, sid, eid)
-    a = O.Acs(og, nb=nb, pheromone_0=par["pheromone_0"])
-    rng = O.srand(rng_seed & 0x7FFFFFFF)
-    tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.REF, rng=rng, alpha=par["alpha"], beta=par["beta"], rho=par["rho"],
-                 pheromone_0=par["pheromone_0"])
-    t = s.trace()
-    assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(t["colony"], tr["colony"]) and np.array_equal(t["finite"], tr["finite"])
-    assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))
+    assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(t["finite"], tr["finite"])
+    assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(t["colony"], tr["colony"])
     cost, path, ch = s.result()
     assert bits(cost) == bits(a.best_L)
     if np.isfinite(cost):
         assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
     assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
-    st = s.rand_state()   # the libc stream is where the oracle's is
-    assert [int(v) for v in st[:31]] == [int(v) for v in rng.r[:31]] and (int(st[34]), int(st[35])) == (int(rng.f), int(rng.b))   # 31 state words, front / back index
     s.close()
     dg.close()
 
 
-# ------------------------------------------------------------------ voxelisation (a3 / N1)
-@pytest.mark.parametrize("seed", range(400, 424))
-def test_random_mesh_voxelisation_equals_the_oracle(ctx, seed):
-    rs = np.random.RandomState(seed)
-    nt = int(rs.randint(1, 120))
-    v = rs.uniform(-1, 1, (nt, 3, 3)).astype(np.float32) * np.float32(rs.choice([1.0, 0.05, 30.0]))
-    k = rs.rand(nt)
-    v[k < 0.3] = v[k < 0.3][:, :1] + rs.uniform(-0.06, 0.06, (int((k < 0.3).sum()), 3, 3)).astype(np.float32)   # small triangles
-    ax = int(rs.randint(0, 3))
-    flat = (k >= 0.3) & (k < 0.45)
-    v[flat, :, ax] = v[flat, :1, ax]                                                                              # axis-aligned ones
-    if nt > 4:
-        v[1] = v[1, 0]            # a point
-        v[2, 2] = v[2, 1]         # a segment
-    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
-    with np.errstate(invalid="ignore", divide="ignore"):
-        n = n / np.linalg.norm(n, axis=1, keepdims=True)
-    tris = np.zeros((nt, 12), np.float32)
-    tris[:, :3] = n
-    tris[:, 3:] = v.reshape(nt, 9)
-    ext = float((v.max(axis=(0, 1)) - v.min(axis=(0, 1))).max())
-    p = max(ext, 1e-3) / float(rs.randint(3, 40))
-    wall = int(rs.randint(0, 6))
-    og = O.grid_from_mesh(tris, p, wall)
-    a = api.Grid.from_mesh(ctx, tris, p, wall)
-    os.environ["WA_VOXELIZE_DENSE"] = "1"
-    try:
-        b = api.Grid.from_mesh(ctx, tris, p, wall)
-    finally:
-        del os.environ["WA_VOXELIZE_DENSE"]
-    assert (a.nx, a.ny, a.nz) == (og.nx, og.ny, og.nz) == (b.nx, b.ny, b.nz)
-    cx, cy, cz = a.coords()
-    assert np.array_equal(bits(cx), bits(og.cx)) and np.array_equal(bits(cy), bits(og.cy)) and np.array_equal(bits(cz), bits(og.cz))
-    assert np.array_equal(a.occupancy(), og.free) and np.array_equal(b.occupancy(), og.free)
-    a.close()
-    b.close()
-
-
-# ------------------------------------------------------------------ seam ordering (a13-a15)
-@pytest.mark.parametrize("seed", range(500, 524))
-def test_random_seam_ordering_equals_the_oracle(ctx, seed):
-    rs = np.random.RandomState(seed)
-    n = int(rs.randint(2, 90))
-    P = rs.uniform(0, 1, (n, 3)) * float(rs.choice([1.0, 100.0, 0.01]))
-    if n > 6 and rs.rand() < 0.5:
-        P[int(rs.randint(0, n))] = P[int(rs.randint(0, n))]            # two cities in one place: zero distance, ties
-    d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1) if rs.rand() < 0.5 else np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
-    cap = int(rs.choice([0, 0, 5, 17]))
-    sd, stream = int(rs.randint(1, 1 << 30)), int(rs.randint(0, 16))
-    o = O.gtsp_solve(d, mode=O.DEV, seed=sd, stream=stream, max_iterations=cap, want_pher=True)
-    for wave in ("1", "0"):
-        os.environ["WA_GTSP_WAVE"] = wave
+@pytest.mark.parametrize("chunk", range(CHUNKS))
+def test_random_problems_dense_lazy_and_26(ctx, chunk):
+    rs = np.random.RandomState(1000 + chunk)
+    for i in range(10):
+        og, sid, eid, par, fixed, predict, iters, seed, stream = random_case(rs)
+        hl = str(int(rs.choice([6, 8, 11])))
+        os.environ["WA_HASH_LOG2"] = hl          # small tables: the bitmap spill path gets its share
         try:
-            t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=sd, stream=stream, max_iterations=cap, want_pher=True)
+            bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+            lazy_ok = bound <= 2048 and int(0.2 * bound) + 1 <= 64
+            for nb, lazy in ((6, False), (6, True), (26, False)):
+                if lazy and not lazy_ok:
+                    continue
+                try:
+                    check(ctx, og, sid, eid, par, fixed, predict, iters, seed, stream, nb, lazy)
+                except AssertionError as e:
+                    raise AssertionError("chunk %d case %d nb %d lazy %s dims %dx%dx%d par %s fixed %d predict %g iters %d hash %s: %s" % (
+                        chunk, i, nb, lazy, og.nx, og.ny, og.nz, par, fixed, predict, iters, hl, e))
         finally:
-            del os.environ["WA_GTSP_WAVE"]
-        assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"], (n, wave)
-        assert np.array_equal(t["edges"][0], o["edges"]), (n, wave)
-        assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), (n, wave)
-    rng = O.srand(sd & 0x7FFFFFFF)                                      # the reference's own stream
-    st = np.array(list(rng.r) + [rng.f, rng.b], np.int32)
-    o = O.gtsp_solve(d, mode=O.REF, rng=rng, max_iterations=cap or 40)
-    t = api.gtsp_solve(ctx, d, mode=api.RNG_REF, rand_state=st, max_iterations=cap or 40)
-    assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
-    assert [int(v) for v in t["rand_state"][:31]] == list(rng.r)[:31]
+            del os.environ["WA_HASH_LOG2"]
 
 
-# ------------------------------------------------------------------ B-spline smoothing (N3)
-def nbits(a):
-    a = np.ascontiguousarray(a, np.float32)
-    b = a.view(np.uint32).ravel().copy()
-    b[np.isnan(a).ravel()] = 0x7fc00000        # NaNs compare equal whatever their sign / payload
-    return b
+# ---------------------------------------------------------------- the other kernels, same idea
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
+def test_random_meshes_voxelise_and_resolve(ctx, chunk):
+    rs = np.random.RandomState(2000 + chunk)
+    for i in range(6):
+        nt = int(rs.randint(1, 40))
+        scale = float(rs.choice([0.05, 1.0, 30.0]))
+        v = (rs.uniform(-1, 1, (nt, 3, 3)) * scale).astype(np.float32)
+        if rs.rand() < 0.5:
+            v = v[:, :1] + (rs.uniform(-0.15, 0.15, (nt, 3, 3)) * scale).astype(np.float32)   # small triangles
+        nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        tris = np.zeros((nt, 12), np.float32)
+        tris[:, :3] = nrm
+        tris[:, 3:] = v.reshape(nt, 9)
+        ext = float(np.ptp(v.reshape(-1, 3), axis=0).max())
+        p = max(ext / float(rs.randint(3, 40)), 1e-4 * scale)
+        wall = int(rs.randint(0, 6))
+        og = O.grid_from_mesh(tris, p, wall)
+        if og.n > 400000:
+            continue
+        dg = api.Grid.from_mesh(ctx, tris, p, wall)
+        assert (dg.nx, dg.ny, dg.nz) == (og.nx, og.ny, og.nz), (chunk, i)
+        assert np.array_equal(dg.occupancy(), og.free), (chunk, i, nt, p, wall)
+        pts = np.stack([rs.choice(og.cx, 12), rs.choice(og.cy, 12), rs.choice(og.cz, 12)], axis=1).astype(np.float32)
+        pts += rs.uniform(-1.5 * p, 1.5 * p, pts.shape).astype(np.float32)
+        assert np.array_equal(dg.resolve(pts), np.array([og.resolve(q) for q in pts])), (chunk, i)
+        dg.close()
 
 
-@pytest.mark.parametrize("seed", range(600, 632))
-def test_random_bspline_equals_the_oracle(ctx, seed):
-    rs = np.random.RandomState(seed)
-    dim, deg = int(rs.randint(1, 17)), int(rs.randint(0, 8))
-    ci, cf = int(rs.randint(0, deg + 1)), int(rs.randint(0, deg + 1))
-    n = int(rs.randint(max(2, deg), 3000))
-    tf = float(rs.choice([1.0, 150.0, 6000.0, 0.37]))
-    mid = (np.cumsum(rs.uniform(-0.01, 0.01, size=(n, dim)), axis=0) * float(rs.choice([1.0, 1000.0]))).astype(np.float32)
-    init = rs.uniform(-1, 1, size=(ci + 1, dim)).astype(np.float32)
-    fin = rs.uniform(-1, 1, size=(cf + 1, dim)).astype(np.float32)
-    ob = O.Bspline(dim, deg, ci, cf, n)
-    ob.set_param(init, fin, mid, tf)
-    b = api.Bspline(ctx, dim, deg, ci, cf, n)
-    b.set_param(init, fin, mid, tf)
-    knots, cps = b.arrays()
-    assert np.array_equal(nbits(knots), nbits(ob.knots)) and np.array_equal(nbits(cps), nbits(ob.cps))
-    count = int(rs.randint(1, 5000))
-    t0, dt = np.float32(-0.02 * tf), np.float32(1.05 * tf / count)
-    for der in sorted({0, min(1, deg), deg, deg + 1}):
-        got, ok = b.sample(t0, dt, count, der)
-        want, wok = ob.sample(t0, dt, count, der, prefill=0.0)
-        assert np.array_equal(ok, wok) and np.array_equal(nbits(got), nbits(want)), der
-    us = np.concatenate([rs.uniform(-0.5 * tf, 1.5 * tf, size=500), [0.0, tf, tf / 2]]).astype(np.float32)   # incl. both ends exactly
-    got, ok = b.eval(us)
-    want, wok = ob.eval(us, prefill=0.0)
-    assert np.array_equal(ok, wok) and np.array_equal(nbits(got), nbits(want))
-    b.close()
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
+def test_random_splines(ctx, chunk):
+    rs = np.random.RandomState(3000 + chunk)
+    for i in range(10):
+        dim, deg = int(rs.randint(1, 8)), int(rs.randint(0, 8))
+        ci, cf = int(rs.randint(0, deg + 1)), int(rs.randint(0, deg + 1))
+        n = int(rs.randint(max(0, deg - ci - cf - 1), 400))
+        if deg + n + 2 + ci + cf + 1 < 2 * (deg + 1):
+            continue
+        tf = float(np.float32(rs.choice([1.0, 150.0, 6000.0, 0.37])))
+        mid = np.cumsum(rs.uniform(-0.05, 0.05, size=(n, dim)), axis=0).astype(np.float32)
+        init = rs.uniform(-1, 1, size=(ci + 1, dim)).astype(np.float32)
+        fin = rs.uniform(-1, 1, size=(cf + 1, dim)).astype(np.float32)
+        fill = int(rs.choice([0, 0x3f800000, 0x7fc00000]))
+        ob = O.Bspline(dim, deg, ci, cf, n, fill)
+        ob.set_param(init, fin, mid, tf)
+        b = api.Bspline(ctx, dim, deg, ci, cf, n, fill)
+        b.set_param(init, fin, mid, tf)
+        k, c = b.arrays()
+
+        def canon(a):   # NaN payloads are not reproduced
+            a = np.ascontiguousarray(a, np.float32)
+            u = a.view(np.uint32).ravel().copy()
+            u[np.isnan(a).ravel()] = 0x7fc00000
+            return u
+        assert np.array_equal(canon(k), canon(ob.knots)) and np.array_equal(canon(c), canon(ob.cps)), (chunk, i, dim, deg, ci, cf, n)
+        us = rs.uniform(-0.1 * tf, 1.1 * tf, size=200).astype(np.float32)
+        for der in sorted({0, min(1, deg), deg}):
+            got, ok = b.eval(us, der)
+            want, wok = ob.eval(us, der, prefill=0.0)
+            assert np.array_equal(ok, wok) and np.array_equal(canon(got), canon(want)), (chunk, i, dim, deg, ci, cf, n, der)
+        b.close()
 
 
-# ------------------------------------------------------------------ batches of searches in one solver (a11 / C4 / C5)
-@pytest.mark.parametrize("seed", range(700, 716))
-def test_random_batch_of_searches_equals_single_oracle_runs(ctx, seed):
-    """Several searches advance together in the slots of one solver (different end points, shared heuristic fields where they coincide,
-    their own DEV streams), twice in a row on the same solver; each must equal the oracle run on its own."""
-    rs = np.random.RandomState(seed)
-    nx, ny, nz = (int(rs.randint(4, 21)) for _ in range(3))
-    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.0, 0.15, 0.3])), seed=seed, p=float(rs.choice([1.0, 0.25])))
-    free = np.flatnonzero(og.free)
-    slots = int(rs.randint(2, 10))
-    lazy = bool(rs.rand() < 0.5)
-    ants = int(rs.randint(2, 40))
-    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
-    sb = api.AcsSolver(ctx, dg, n_slots=slots, max_colony=ants, lazy=lazy)
-    for rnd in range(2):
-        k = slots if rnd == 0 else int(rs.randint(1, slots + 1))         # the second batch may leave slots idle
-        ends = rs.choice(free, min(3, len(free)), replace=False)             # few distinct end points: heuristic fields are shared
-        starts = [int(v) for v in rs.choice(free, k)]
-        endl = [int(v) for v in rs.choice(ends, k)]
-        streams = [int(v) for v in rs.randint(0, 1000, k)]
-        iters, sd = int(rs.randint(1, 30)), int(rs.randint(1, 1 << 30))
-        p = api.default_params(max_iteration=iters, predict=float((nx + ny + nz) * og.precision), fixed_colony=ants, rng_mode=api.RNG_DEV, seed=sd)
-        sb.init_pheromone(1.0)   # (initFromGridMap; reset() also fills the out-of-bounds edges, which the pair-flow goldens cover)
-        sb.solve(p, starts, endl, streams=streams)
-        for q in range(k):
-            a = O.Acs(og)
-            a.solve(starts[q], endl[q], iters, float((nx + ny + nz) * og.precision), fixed_colony=ants, mode=O.DEV, seed=sd, stream=streams[q])
-            cost, path, _ = sb.result(q)
-            assert bits(cost) == bits(a.best_L), (rnd, q)
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_random_seam_ordering(ctx, wave):
+    rs = np.random.RandomState(4000)
+    os.environ["WA_GTSP_WAVE"] = wave
+    try:
+        for i in range(16):
+            n = int(rs.randint(2, 48))
+            P = rs.uniform(0, 1, (n, 3))
+            if rs.rand() < 0.3:
+                P[rs.randint(n)] = P[rs.randint(n)]
+            d = np.abs(P[:, None, :] - P[None, :, :]).sum(-1) if rs.rand() < 0.5 else np.sqrt(((P[:, None, :] - P[None, :, :]) ** 2).sum(-1))
+            d = np.round(d, 3) if rs.rand() < 0.5 else d        # graph.in carries 3 decimals: many exact ties
+            cap = int(rs.choice([0, 0, 1, 7, 30]))
+            seed, stream = int(rs.randint(1 << 30)), int(rs.randint(100))
+            o = O.gtsp_solve(d, mode=O.DEV, seed=seed, stream=stream, max_iterations=cap, want_pher=True)
+            t = api.gtsp_solve(ctx, d, mode=api.RNG_DEV, seed=seed, stream=stream, max_iterations=cap, want_pher=True)
+            assert t["iters"][0] == o["iters"] and t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"]), (i, n, cap)
+            assert np.array_equal(t["pher"][0].view(np.uint64), o["pher"].view(np.uint64)), (i, n, cap)
+    finally:
+        del os.environ["WA_GTSP_WAVE"]
+
+
+@pytest.mark.parametrize("chunk", range(max(3, CHUNKS // 8)))
+def test_random_medium_problems(ctx, chunk):
+    """larger grids and colonies: replay after convergence, > 64 depositing ranks (unfused chunks), > 2048 ants"""
+    rs = np.random.RandomState(5000 + chunk)
+    for i in range(5):
+        n = int(rs.randint(14, 34))
+        og = O.synth_grid(n, seed=int(rs.randint(1 << 20)), occ_prob=float(rs.choice([0.0, 0.1, 0.2])))
+        sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, n - 1, np.float32))
+        par = dict(alpha=int(rs.choice([1, 1, 2])), beta=float(np.float32(rs.choice([0.6, 1.2]))),
+                   rho=float(np.float32(rs.choice([0.8, 0.6]))), pheromone_0=1.0)
+        fixed = int(rs.choice([30, 64, 200, 330, 2100] if i < 4 else [2100]))
+        iters = int(rs.choice([8, 20, 45])) if fixed < 2000 else 3
+        seed, stream = int(rs.randint(1 << 30)), int(rs.randint(9))
+        lazy_ok = fixed <= 2048 and int(0.2 * fixed) + 1 <= 64
+        for nb, lazy in ((6, False), (6, True), (26, False)):
+            if lazy and not lazy_ok:
+                continue
+            if nb == 26 and fixed > 400:
+                continue
+            try:
+                check(ctx, og, sid, eid, par, fixed, 3.0 * n, iters, seed, stream, nb, lazy)
+            except AssertionError as e:
+                raise AssertionError("medium chunk %d case %d nb %d lazy %s n %d par %s fixed %d iters %d: %s" % (chunk, i, nb, lazy, n, par, fixed, iters, e))
+
+
+@pytest.mark.parametrize("chunk", range(CHUNKS4))
+def test_random_problems_ref_mode(ctx, chunk):
+    """WA_RNG_REF (libc stream carried on the device, libstdc++ sort order) against the oracle's REF mode, which the
+    live differential test pins to the reference itself: same draws consumed, same stream position afterwards."""
+    rs = np.random.RandomState(6000 + chunk)
+    for i in range(8):
+        og, sid, eid, par, fixed, predict, iters, seed, stream = random_case(rs)
+        iters = min(iters, 25)
+        for nb in (6, 26):
+            dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+            bound = fixed if fixed else int(0.35 * predict / float(og.precision))
+            s = api.AcsSolver(ctx, dg, 1, max(bound, 1), neighbourhood=nb)
+            s.init_pheromone(par["pheromone_0"])
+            s.srand(seed & 0x7fffffff)
+            p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=fixed, rng_mode=api.RNG_REF, **par)
+            s.solve(p, sid, eid)
+            rng = O.srand(seed & 0x7fffffff)
+            a = O.Acs(og, pheromone_0=par["pheromone_0"], nb=nb)
+            tr = a.solve(sid, eid, iters, predict, fixed_colony=fixed, mode=O.REF, rng=rng, **par)
+            t = s.trace()
+            tag = (chunk, i, nb, og.nx, og.ny, og.nz, par, fixed, predict, iters)
+            assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])), tag
+            cost, path, ch = s.result()
+            assert bits(cost) == bits(a.best_L), tag
             if np.isfinite(cost):
-                assert np.array_equal(path, a.best_path()[0])
-            assert np.array_equal(bits(sb.pheromone(q)), bits(a.pheromone())), (rnd, q)
-    sb.close()
-    dg.close()
-
-
-@pytest.mark.parametrize("seed", range(800, 816))
-def test_random_medium_search_equals_the_oracle(ctx, seed):
-    """Corner-to-corner searches on 30..64-voxel grids: walks of a few hundred steps (several 64-word path blocks, table collisions),
-    enough generations for the best-path replay and -- from generation 16 on -- the rejoin watch; dense and lazy."""
-    rs = np.random.RandomState(seed)
-    nx, ny, nz = (int(rs.randint(30, 65)) for _ in range(3))
-    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.05, 0.1, 0.2])), seed=seed, p=1.0)
-    og.free[0] = og.free[-1] = 1
-    par = dict(alpha=1, beta=float(rs.choice([0.6, 1.0])), rho=float(rs.choice([0.8, 0.9])), pheromone_0=1.0)
-    run_variant(ctx, og, 0, nx * ny * nz - 1, int(rs.randint(20, 46)), float(nx + ny + nz), int(rs.randint(16, 65)), int(rs.randint(1, 1 << 30)),
-                int(rs.randint(0, 8)), par, lazy=bool(seed & 1))
-
-
-# ------------------------------------------------------------------ the same random searches down the other code paths
-KNOBS = [dict(WA_WALK_ASM="0"),                         # the compiler-scheduled loop instead of the hand-scheduled one
-         dict(WA_WALK_WARM="0"),                        # no touch loads (the saturated-launch variant of the loop)
-         dict(WA_HASH_LOG2="6"),                        # a 64-entry tabu table: probe chains, spill to the global bitmap
-         dict(WA_HASH_LOG2="8", WA_WALK_WARM="0"),
-         dict(WA_REENTRY="0"),                          # no rejoin watch
-         dict(WA_REENTRY_STABLE="1"),                   # ... armed after one stable generation
-         dict(WA_EVAP_BLOCKS="7"), dict(WA_LAZY_BLOCKS="3")]   # odd sweep / background-pass grids
-
-
-@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
-def test_random_searches_down_the_other_code_paths(ctx, knobs, monkeypatch):
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)   # read by wa_acs_create
-    for seed in list(range(0, 96, 8)) + [801, 806, 811]:
-        if seed < 800:
-            og, sid, eid, iters, predict, fixed, rng_seed, stream, par = draw_case(seed)
-            run_variant(ctx, og, sid, eid, iters, predict, fixed, rng_seed, stream, par, lazy=bool(seed & 8))
-        else:
-            rs = np.random.RandomState(seed)
-            nx, ny, nz = (int(rs.randint(30, 65)) for _ in range(3))
-            og = box_grid(nx, ny, nz, occ_prob=0.1, seed=seed, p=1.0)
-            og.free[0] = og.free[-1] = 1
-            run_variant(ctx, og, 0, nx * ny * nz - 1, 24, float(nx + ny + nz), 32, seed, 1, dict(alpha=1, beta=0.6, rho=0.8, pheromone_0=1.0),
-                        lazy=bool(seed & 1))
+                assert np.array_equal(path, a.best_path()[0]), tag
+            assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), tag
+            st = s.rand_state()
+            assert [int(v) for v in st[:31]] == list(rng.r)[:31] and int(st[34]) == rng.f and int(st[35]) == rng.b, tag   # 31 state words
+            s.close()
+            dg.close()
