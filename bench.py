@@ -308,6 +308,7 @@ def c5_full_extra(ctx):
     pts = synth.synth_weld_points(free, n, P, seed=seed)
     t_inputs = time.perf_counter() - t0
     predict = float(24 / 0.35)
+    waited = pb.wait_for_device_memory(ctx)   # (solvers of the earlier extras may still be giving their memory back, see examples/plan_batch.py)
     t0 = time.perf_counter()
     cost, paths, mine = pb.plan(ctx, grid, pts, gens, predict, seed, 0, lazy=True)
     ctx.sync()
@@ -319,7 +320,7 @@ def c5_full_extra(ctx):
     pairs = P * (P - 1) // 2
     return {"workload": "256^3 grid, 64 weld points = %d pair searches x %d generations, 24 ants, lazy evaporation; then the 64-seam order" % (pairs, gens),
             "slots_by_rule": pb.plan.last_slots, "batches": -(-pairs // pb.plan.last_slots), "t_pairs_s": t_pairs, "t_solver_create_s": pb.plan.last_create_s,
-            "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "pair_generations_per_s": pairs * gens / t_pairs,
+            "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "t_memory_wait_s": waited, "pair_generations_per_s": pairs * gens / t_pairs,
             "all_reached": bool(np.isfinite(cost).all()), "tour_cost": float(tour["L"][0]), "tour_iterations": int(tour["iters"][0])}
 
 
@@ -556,7 +557,6 @@ def main():
             solver.run(G)
             solver.sync()
             gpu_first_ms = (time.perf_counter() - t1) * 1e3
-            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl, path, K))
         if world == 1:
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
@@ -565,6 +565,9 @@ def main():
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
             solver.close()
             out["c5_full"] = c5_full_extra(ctx)
+        if world == 1 and not args.no_cpu:
+            # the CPU leg comes last (the extras before it are host-paced: 0.52-0.84 s for the C5 extra from box to box, whatever runs in front)
+            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl, path, K))
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
