@@ -55,10 +55,21 @@ struct WaAcsDev {
     uint32_t *stamp;               // [slot][n]
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
+    // stragglers (single-search dense solvers, colony <= 256; all null otherwise): an ant that can no longer be among the depositing ranks
+    // nor become the best path leaves its launch at a 64-step block boundary and is finished by a resume block of the NEXT generation's
+    // walk launch, on the previous generation's field (see k_walk_dev)
+    uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (0xffffffff = none yet)
+    uint32_t *arr_n;               // [1]
+    int32_t *pool_n;               // [2]   stragglers of generation g in pool [g & 1]
+    int32_t *pool_rec;             // [2][WA_RESUME_MAX][2]  (ant, node count at the hand-over)
+    int32_t *pool_path;            // [2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
+    const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
 };
+
+#define WA_RESUME_MAX 64
 
 // rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
 struct WaMaskRef {
@@ -179,6 +190,11 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.flags = 0;
     wa_next_params(c, R, 0);
     D.ctl[slot] = c;
+    if (D.pool_n && slot == 0) {
+        D.pool_n[0] = D.pool_n[1] = 0;
+        *D.arr_n = 0;
+        for (int i = 0; i < 256; i++) D.arr_len[i] = 0xffffffffu;
+    }
 }
 
 
@@ -704,19 +720,29 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t &rng_rs, int32_t &rng_f, int32_t &rng_b,
                                             int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags,
-                                            uint32_t best_ver, int32_t heur_slot)
+                                            uint32_t best_ver, int32_t heur_slot, int32_t cut_n = 0x7fffffff, const int32_t *res_words = nullptr,
+                                            int32_t res_len = 0, int32_t gen = 0, int32_t bits_row = -1)
 {
+    // cut_n: straggler check (0x7fffffff = off).  res_words / res_len: this block RESUMES a straggler of the previous generation -- the
+    // walk continues behind its res_len nodes (D.pher is then that generation's field, rlen 0, no rejoin watch) and only its statistics
+    // are delivered (the ant's slot in agents[] belongs to the running generation's ant by now)
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)heur_slot * D.pher_stride;   // (the caller read it with the rest of the control block)
     const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
     const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
-    int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    int32_t *path = res_words ? const_cast<int32_t *>(res_words) : D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
     const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
     WaWalkState st;
     st.cur = start; st.len = 1; st.step = 0; st.L = 0.f; st.done = false; st.pbuf = 0; st.pbuf_valid = false;
     const int32_t *prefix_words = nullptr;
-    if (MODE == 1 && rlen > 1) {
+    if (res_words) {
+        st.len = res_len;
+        st.cur = __builtin_amdgcn_readfirstlane(res_words[res_len - 1] & (int32_t)WA_ID_MASK);
+        st.step = (uint32_t)(res_len - 1);
+        for (int32_t q = 0; q < res_len - 1; q++) st.L += R.precision;   // :78, one add per step taken
+        prefix_words = res_words;
+    } else if (MODE == 1 && rlen > 1) {
         int32_t node = 0;
         // the first 512 words of the best path are requested BEFORE the replay decides how many of them the ant walks: their round trip
         // runs beside the table rows' (once converged every ant copies all of them)
@@ -761,6 +787,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+                if (what == 2 && cut_n != 0x7fffffff) D.arr_len[atomicAdd(D.arr_n, 1u) & 255u] = (uint32_t)st.len;   // an arrival, for the straggler check
             }
             return;
         }
@@ -773,7 +800,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     T.tab = tab;
     T.mask = (1u << hash_log2) - 1u;
     T.shift = 32 - hash_log2;
-    T.bits = D.vbits + ((int64_t)slot * D.max_colony + ant) * D.vbits_words;
+    // (a resume block spills into a bitmap row of its own, behind the ants' rows: the ant's row belongs to the running generation's ant)
+    T.bits = D.vbits + ((int64_t)slot * D.max_colony + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
 
@@ -786,7 +814,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         // tabu set := the replayed prefix.  Distinct keys, no deletions: any insertion order gives a valid
         // open-addressing table, so the lanes insert concurrently with compare-and-swap on the slot.
         for (int32_t q = lane; q < st.len; q += 64) {
-            const int32_t key = bpath[q] & (int32_t)WA_ID_MASK;
+            const int32_t key = prefix_words[q] & (int32_t)WA_ID_MASK;
             uint32_t h = ((uint32_t)key * 2654435761u) >> T.shift;
             while (atomicCAS(&tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & T.mask;
         }
@@ -799,6 +827,27 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #ifndef WA_STAMPS
     use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
 #endif
+    // ---- a straggler (the loop left through its check, st.reason == 5): its path so far goes to a pool entry of its generation; agents[]
+    // says "not arrived, st.len nodes" (what the ranking sees); a resume block of the next walk launch finishes it and adds the rest to
+    // the generation's statistics.  False when the pool is full: the ant walks on without the check.
+    auto hand_over = [&]() -> bool {
+        int32_t r = 0;
+        if (lane == 0) r = atomicAdd(&D.pool_n[gen & 1], 1);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= WA_RESUME_MAX) {
+            if (lane == 0) atomicSub(&D.pool_n[gen & 1], 1);
+            return false;
+        }
+        int32_t *pp = D.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
+        for (int32_t q = lane; q < st.len; q += 64) pp[q] = path[q];
+        if (lane == 0) {
+            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2] = ant;
+            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2 + 1] = st.len;
+            D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
+            D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+        }
+        return true;
+    };
     if (REJ && st.len < fast_limit && use_asm && prefix_words && (walk_flags & 2)) {
         // The ant replayed a prefix of the best path and left it.  Measured: such an ant is back on the path after a
         // median of 3-4 steps and 82-92 % of its remaining nodes lie on it, so the general loop runs with a rejoin watch and every
@@ -821,12 +870,13 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #endif
         for (;;) {
             wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
-                                             D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold);
+                                             D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold,
+                                             SPARSE ? nullptr : D.arr_len, cut_n);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
 #ifdef WA_ANT_TIME
             if (dbg_t_hand) { dbg_t_hand = 0; }
 #endif
-            if (st.done || st.reason != 4) break;
+            if (st.done || st.reason != 4) break;   // (5: a straggler, handed over below)
 #ifdef WA_ANT_TIME
             dbg_hand++;
             const unsigned long long dbg_t0 = __builtin_readcyclecounter();
@@ -880,11 +930,17 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             atomicAdd(&D.dbg[15], 1ULL);
         }
 #endif
-        if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it
+        if (!st.done && st.reason == 5 && hand_over()) return;
+        if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it (also behind a full pool)
     } else if (st.len < fast_limit && use_asm) {
         WA_PHASE(8);
         wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
-                                 D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr);
+                                 D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr,
+                                 nullptr, 0, 0, SPARSE ? nullptr : D.arr_len, cut_n);
+        if (!st.done && st.reason == 5) {
+            if (hand_over()) return;
+            st.L = D.ltab[st.len - 1];              // the pool is full: the generic loop finishes this ant
+        }
     }
     else if (st.len < fast_limit)
         wa_walk_fast<MODE, ALPHA1, SPARSE>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.d.n, (int32_t)D.path_cap, end, antkey,
@@ -898,9 +954,18 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     }
     WA_PHASE(9);
     if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out);
+    if (res_words) {   // a resumed straggler: the rest of its walk belongs to generation `gen`'s statistics
+        if (lane == 0 && gen < D.trace_cap) {
+            const int64_t t = (int64_t)slot * D.trace_cap + gen;
+            if (st.L != INFINITY) atomicAdd(&D.trFinite[t], 1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(st.len - res_len));
+        }
+        return;
+    }
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+        if (st.L != INFINITY && cut_n != 0x7fffffff) D.arr_len[atomicAdd(D.arr_n, 1u) & 255u] = (uint32_t)st.len;   // an arrival, for the straggler check
     }
 }
 
@@ -1024,6 +1089,10 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
     const int32_t slot = blockIdx.y;
     // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
     if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
+    if (D.pool_n && blockIdx.x == 0) {   // stragglers: the next generation starts with no arrivals and an empty pool of its own
+        D.arr_len[threadIdx.x] = 0xffffffffu;
+        if (threadIdx.x == 0) { *D.arr_n = 0; D.pool_n[D.ctl[slot].gen & 1] = 0; }   // (ctl.gen is already the next generation's number)
+    }
     if ((int32_t)blockIdx.x < table_blocks) {
         // independent loads first: deposit coefficients, control block, this row's path words
         const int32_t tid = threadIdx.x, row0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1053,6 +1122,21 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
+    if (!SPARSE && ALPHA1 && D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
+        // ---- resume block: a straggler of generation gen - 1 (walk_flags bit 5 allowed it to leave that launch) finishes its walk here,
+        // on that generation's field, beside this generation's ants; only that generation's statistics hear of it
+        const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
+        if (gen < 1 || r >= D.pool_n[pg] || r >= WA_RESUME_MAX) return;
+        const int32_t a = D.pool_rec[(pg * WA_RESUME_MAX + r) * 2], n0 = D.pool_rec[(pg * WA_RESUME_MAX + r) * 2 + 1];
+        WaAcsDev Dp = D;
+        Dp.pher = const_cast<float *>(D.prev_pher);
+        const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
+        int32_t f0 = 0, b0 = 0, rs0 = 0;
+        wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
+                                                 walk_flags & 1, 0u, c->heur_slot, 0x7fffffff, D.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
+                                                 D.max_colony + r);
+        return;
+    }
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0, rs_unused = 0;
@@ -1065,8 +1149,13 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const unsigned long long t0_ = __builtin_readcyclecounter();
     if (slot == 0 && ant == 0 && threadIdx.x == 0 && D.dbg) atomicAdd(&D.dbg[5], t0_);
 #endif
+    // the straggler check (walk_flags bit 5; never in the last generation of a wa_acs_run call): an ant longer than floor(lambda - 1) + 1
+    // arrivals cannot be among the depositing ranks (:200) nor be the iteration's best
+    int32_t cut_n = 0x7fffffff;
+    if (!SPARSE && ALPHA1 && (walk_flags & 32) && D.pool_n) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
+    if (cut_n < 1) cut_n = 1;
     wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
-                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot);
+                                   c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot, cut_n, nullptr, 0, gen);
 #ifdef WA_ANT_TIME
     if (threadIdx.x == 0 && D.dbg) {
         if (slot == 0 && ant == 0) atomicAdd(&D.dbg[10], (unsigned long long)__builtin_readcyclecounter());

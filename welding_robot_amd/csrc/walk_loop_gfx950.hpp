@@ -447,8 +447,34 @@
 #define WA_ASM_STAMPS_DUMP ""
 #define WA_ASM_STAMPS_CLOBBER
 #endif
+// The straggler check (dense loops, one search per solver): at a block boundary an ant whose node count already exceeds that of %[cutn]
+// arrivals of its generation cannot be among the depositing ranks nor become the best path any more; it leaves with code 5 and is
+// finished beside the next generation's ants (see k_walk_dev).  %[cut] = node counts of the arrivals so far (0xffffffff = none yet),
+// lane l looks at entries l, l+64, l+128, l+192; %[cutn] = 0x7fffffff switches the check off.  v86..v89 are the touch loads' registers
+// (nobody reads those): the loads in flight are drained first.
+#define WA_ASM_CUT                                                                                                \
+    "s_cmp_eq_u32 %[cutn], 0x7fffffff\n"                                                                          \
+    "s_cbranch_scc1 Lwa_nocut%=\n"                                                                                \
+    "s_waitcnt vmcnt(0)\n"                                                                                        \
+    "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
+    "global_load_dword v86, v94, %[cut] sc1\n"                                                                    \
+    "global_load_dword v87, v94, %[cut] offset:256 sc1\n"                                                         \
+    "global_load_dword v88, v94, %[cut] offset:512 sc1\n"                                                         \
+    "global_load_dword v89, v94, %[cut] offset:768 sc1\n"                                                         \
+    "s_mov_b32 s46, m0\n"                                                                                         \
+    "s_waitcnt vmcnt(0)\n"                                                                                        \
+    "v_cmp_gt_u32 vcc, s46, v86\n s_nop 4\n s_bcnt1_i32_b64 s58, vcc\n"                                          \
+    "v_cmp_gt_u32 vcc, s46, v87\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
+    "v_cmp_gt_u32 vcc, s46, v88\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
+    "v_cmp_gt_u32 vcc, s46, v89\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
+    "s_cmp_ge_u32 s58, %[cutn]\n"                                                                                 \
+    "s_cbranch_scc0 Lwa_nocut%=\n"                                                                                \
+    "s_mov_b32 %[code], 5\n"                                                                                      \
+    "s_branch Lwa_out%=\n"                                                                                        \
+    "Lwa_nocut%=:\n"
 // everything behind the loop: the dead-end exit and the pending-event handler (a completed 64-word block and/or the arrival)
-#define WA_ASM_TAIL                                                                                               \
+#define WA_ASM_TAIL WA_ASM_TAIL_("")
+#define WA_ASM_TAIL_(CUT)                                                                                         \
     "Lwa_dead%=:\n"                                                                                               \
     "s_mov_b32 %[code], 1\n"                                                                                      \
     "s_branch Lwa_out%=\n"                                                                                        \
@@ -468,6 +494,7 @@
     "s_add_i32 s46, m0, 64\n"                                                                                     \
     "s_cmp_gt_i32 s46, %[limit]\n"                                                                                \
     "s_cbranch_scc1 Lwa_out%=\n"                   /* the next block would pass the table-load / capacity limit: the caller's generic loop goes on */ \
+    CUT                                                                                                           \
     "v_add_u32 v94, m0, v64\n"                     /* the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw) */ \
     "v_add_u32 v94, -1, v94\n"                                                                                    \
     "s_mov_b32 s46, 0x9e3779b9\n"                                                                                 \
@@ -547,10 +574,10 @@
         "s_branch Lwa_top%=\n"                                                                                    \
         WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
-        WA_ASM_TAIL                                                                                               \
+        WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
-          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32))                    \
+          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [cut] "s"(cut_list), [cutn] "s"(cut_n) \
         : WA_ASM_CLOBBERS);
 #define WA_ASM_RUN_REJ(W)                                                                                         \
     asm volatile(                                                                                                 \
@@ -567,10 +594,10 @@
         WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_REJ_EXITS                                                                                          \
-        WA_ASM_TAIL                                                                                               \
+        WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
-          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark)  \
+          [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark), [cut] "s"(cut_list), [cutn] "s"(cut_n) \
         : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 // the lazy-field loop as a statement (STEP = WA_ASM_STEP_LAZY or WA_ASM_STEP_LAZY_REJ; REJINIT / REJEXITS = the rejoin watch's
 // set-up and hand-back stubs, empty without it; `mark` is passed either way)
@@ -620,8 +647,11 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                                                  int32_t path_cap, int32_t end, uint64_t antkey, int32_t spill_at,
                                                  int32_t guard_bytes, int32_t stamp_guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
                                                  int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg,
-                                                 const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0)
+                                                 const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0,
+                                                 const uint32_t *cut_list = nullptr, int32_t cut_n = 0x7fffffff)
 {
+    if (!cut_list) cut_n = 0x7fffffff;   // straggler check off (see WA_ASM_CUT); st.reason = 5 when the ant left through it
+    cut_n = __builtin_amdgcn_readfirstlane(cut_n);   // (an SGPR operand of the loop: neither a literal nor a lane value)
     constexpr bool LAZY = VARIANT == 1 || VARIANT == 3, REJOIN = VARIANT == 2 || VARIANT == 3;
     const int lane = threadIdx.x;
     const int j = lane >> 3, pos = lane & 7;
@@ -665,7 +695,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     }
     uint32_t pd = LAZY ? stamp[cur] : 1u;
     const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
-    int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on
+    int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on, 5 straggler
     for (;;) {
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
         if ((len | 63) + 1 > limit) { exit_code = 3; break; }
@@ -703,10 +733,11 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
 #if defined(WA_ASM_STAMPS)
     if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
 #endif
-    st.done = exit_code != 3 && exit_code != 4;
+    if (exit_code == 5) st.reason = 5;
+    st.done = exit_code != 3 && exit_code != 4 && exit_code != 5;
     // :78, one add of `precision` per step taken (table).  A walk handed back by the rejoin watch does not need it yet: the
     // load would sit on the path of every re-entry
-    float L = exit_code == 1 ? INFINITY : exit_code == 4 ? 0.f : ltab[len - 1];
+    float L = exit_code == 1 ? INFINITY : (exit_code == 4 || exit_code == 5) ? 0.f : ltab[len - 1];
     if (!st.done && len >= path_cap) {                     // the next step would not fit path[]
         if (lane == 0) atomicOr(flags_out, WA_FLAG_PATH_OVERFLOW);
         L = INFINITY;

@@ -69,7 +69,7 @@ struct wa_acs {
     bool lazy;                          // lazy evaporation (wa_acs_create_lazy): never-deposited voxels are not swept
     std::vector<int> lazy_mode;         // per slot: init mode of the stored records (-1 unknown)
     std::vector<float> lazy_p0;
-    int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks, lazy_blocks_env;
+    int32_t gens_enqueued, colony_bound, hash_log2, evap_blocks, lazy_blocks_env, straggler_gens = 64;
     long long *d_starts, *d_ends;
     uint32_t *d_streams;
     int32_t *d_hslot, *d_hlist, *d_hends;   // per search: the heuristic field it reads / the fields wa_acs_begin computes and their end points
