@@ -196,8 +196,16 @@ enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_
  * operation, so the timed loop is not perturbed -- what bench.py's roofline figure uses) */
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
-/* diagnostic cycle counters of the walk's inner loop: all zero unless the library was built with
- * -DWA_STAMPS (tools/walk_stamps.py); never enabled in the product build */
+/* diagnostic counters.  Product build: out16[9] = ants handed over as stragglers, out16[7] = stragglers finished by a resume block (the two
+ * are equal after wa_acs_run returns), everything else zero; the cycle counters of the walk's inner loop only exist in the diagnostic
+ * builds (-DWA_STAMPS / -DWA_ANT_TIME, tools/).
+ * Stragglers (a single dense 6-neighbour search of at most 256 ants, DEV mode, alpha == 1, the first 64 generations of a search): only the
+ * ranks o <= lambda - 1 deposit (ACSRank_3D.hpp:200) and only the shortest ant can become the best path (:263-264), so an ant that is
+ * already longer than floor(lambda - 1) + 1 arrivals of its generation can change neither; at a 64-step block boundary it leaves the walk
+ * launch -- which lasts as long as its longest ant -- and a resume block of the NEXT generation's walk launch finishes the same walk on the
+ * previous generation's field (intact until the next sweep), adding its arrival and its steps to its own generation's trace entry.  The
+ * last generation of a wa_acs_run call hands nothing over, so agents[] and the trace are complete when the call's work is.  Results are
+ * bit-identical with the mechanism on or off (WA_STRAGGLERS=0, read at wa_acs_create). */
 int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
 /* evaporation sweep alone (ACSRank_3D.hpp:268-272) over `slot` -- for roofline measurements */
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats);

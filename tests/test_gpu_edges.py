@@ -317,3 +317,46 @@ def test_profile_can_stamp_the_sweep_launch_of_every_generation(ctx):
     s.profile(True, 5)
     s.run(0)
     s.close()
+
+
+def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
+    """A single dense search hands ants that can no longer matter to resume blocks of the next walk launch (include/weldacs.h,
+    wa_acs_debug_counters).  With the mechanism on, off, and run generation by generation (where it never engages): the same trace --
+    steps and finite ants included --, the same ants in the last generation, the same field, all equal to the oracle."""
+    og = box_grid(48, 40, 44, occ_prob=0.1, seed=21)
+    og.free[0] = og.free[-1] = 1
+    n = 48 * 40 * 44
+    out = np.zeros(16, np.uint64)
+    res = {}
+    for mode in ("on", "off", "stepwise"):
+        monkeypatch.setenv("WA_STRAGGLERS", "0" if mode == "off" else "1")
+        dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+        s = api.AcsSolver(ctx, dg, 1, 96)
+        p = api.default_params(max_iteration=14, predict=132.0, fixed_colony=96, rng_mode=api.RNG_DEV, seed=77)
+        s.init_pheromone(1.0)
+        ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 1))
+        if mode == "stepwise":
+            s.begin(p, 0, n - 1, streams=[4])
+            for _ in range(14):
+                s.run(1)
+            s.sync()
+        else:
+            s.solve(p, 0, n - 1, streams=[4])
+        ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
+        handed, resumed = int(out[9]), int(out[7])
+        if mode == "on":
+            assert handed > 0 and resumed == handed       # it engaged, and every straggler was finished
+        else:
+            assert handed == 0 and resumed == 0
+        t = s.trace()
+        L, lens = s.ants()
+        res[mode] = (t["steps"].copy(), t["finite"].copy(), bits(t["bestL"]), bits(L), lens.copy(), bits(s.pheromone()))
+        s.close()
+        dg.close()
+    a = O.Acs(og)
+    tr = a.solve(0, n - 1, 14, 132.0, fixed_colony=96, mode=O.DEV, seed=77, stream=4)
+    olens, oL = a.last_ants()
+    want = (tr["steps"], tr["finite"], bits(tr["bestL"]), bits(oL), olens, bits(a.pheromone()))
+    for mode in res:
+        for got, w in zip(res[mode], want):
+            assert np.array_equal(got, w), mode

@@ -845,6 +845,9 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2 + 1] = st.len;
             D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
             D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+#ifndef WA_ANT_TIME
+            if (D.dbg) atomicAdd(&D.dbg[9], 1ULL);   // ants handed over since the counters were last reset (wa_acs_debug_counters)
+#endif
         }
         return true;
     };
@@ -955,6 +958,9 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     WA_PHASE(9);
     if (!st.done) wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out);
     if (res_words) {   // a resumed straggler: the rest of its walk belongs to generation `gen`'s statistics
+#ifndef WA_ANT_TIME
+        if (lane == 0 && D.dbg) atomicAdd(&D.dbg[7], 1ULL);   // ... and stragglers finished by a resume block
+#endif
         if (lane == 0 && gen < D.trace_cap) {
             const int64_t t = (int64_t)slot * D.trace_cap + gen;
             if (st.L != INFINITY) atomicAdd(&D.trFinite[t], 1);
