@@ -444,6 +444,8 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    dbg16 = np.zeros(16, np.uint64)
+    ctx.check(ctx.lib.wa_acs_debug_counters(solver.h, dbg16.ctypes.data, 1))   # (reset: stragglers handed over / resumed in the timed region)
     barrier()
     t0 = time.perf_counter()
     done = 0
@@ -467,6 +469,10 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = wd.max_over_ranks(elapsed, dev)
     total_gens = wd.sum_over_ranks(K, dev)
+    ctx.check(ctx.lib.wa_acs_debug_counters(solver.h, dbg16.ctypes.data, 0))
+    stragglers = {"handed_over": int(dbg16[9]), "finished_by_resume_blocks": int(dbg16[7]),
+                  "note": "ants that could no longer be among the depositing ranks left their walk launch at a block boundary and were finished "
+                          "beside the next generation's ants on the previous generation's field (DESIGN 4e): every step taken, the two counts are equal"}
 
     prof = solver.profile_read()
     cost, path, _ = solver.result()
@@ -542,7 +548,7 @@ def main():
                                          "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None, "traffic_256": traffic_256, "sweep_256": r256},
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
-            "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
+            "stragglers": stragglers, "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
             "device": ctx.device_name,
         }

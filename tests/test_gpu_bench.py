@@ -50,4 +50,6 @@ def test_bench_json_contract():
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     cc = d["cost_check"]   # all 60 timed generations replayed by the CPU port: history and final best path equal
     assert cc["bit_equal_trace"] is True and cc["generations"] == 60 and cc["best_path_equal"] is True
+    sg = d["stragglers"]   # the hand-over engaged in the timed region and every straggler was finished
+    assert sg["handed_over"] > 0 and sg["handed_over"] == sg["finished_by_resume_blocks"]
     assert abs(d["ms_per_step"] * d["value"] / 1e3 - 1.0) < 1e-6
