@@ -360,3 +360,33 @@ def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
     for mode in res:
         for got, w in zip(res[mode], want):
             assert np.array_equal(got, w), mode
+
+
+@pytest.mark.parametrize("chunks", [(2,), (3,), (2, 2, 1, 3), (5, 1, 4)])
+def test_straggler_hand_over_across_run_boundaries(ctx, chunks):
+    """wa_acs_run in pieces: the last generation of every call hands nothing over, the others may; the search is the oracle's whatever the split."""
+    og = box_grid(48, 40, 44, occ_prob=0.1, seed=21)
+    og.free[0] = og.free[-1] = 1
+    n, total = 48 * 40 * 44, sum(chunks)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, 1, 96)
+    p = api.default_params(max_iteration=total, predict=132.0, fixed_colony=96, rng_mode=api.RNG_DEV, seed=78)
+    s.init_pheromone(1.0)
+    s.begin(p, 0, n - 1, streams=[2])
+    for c in chunks:
+        s.run(c)
+        s.sync()
+        out = np.zeros(16, np.uint64)
+        ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
+        assert int(out[9]) == int(out[7])                 # nothing is left over between calls
+    a = O.Acs(og)
+    tr = a.solve(0, n - 1, total, 132.0, fixed_colony=96, mode=O.DEV, seed=78, stream=2)
+    t = s.trace()
+    assert np.array_equal(t["steps"][:total], tr["steps"]) and np.array_equal(t["finite"][:total], tr["finite"])
+    assert np.array_equal(bits(t["bestL"][:total]), bits(tr["bestL"]))
+    L, lens = s.ants()
+    olens, oL = a.last_ants()
+    assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL))
+    assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+    s.close()
+    dg.close()
