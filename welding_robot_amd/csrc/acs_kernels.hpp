@@ -69,7 +69,7 @@ struct WaAcsDev {
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
 };
 
-#define WA_RESUME_MAX 64
+#define WA_RESUME_MAX 256
 
 // rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
 struct WaMaskRef {
@@ -787,7 +787,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-                if (what == 2 && cut_n != 0x7fffffff) D.arr_len[atomicAdd(D.arr_n, 1u) & 255u] = (uint32_t)st.len;   // an arrival, for the straggler check
+                if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
             }
             return;
         }
@@ -971,7 +971,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-        if (st.L != INFINITY && cut_n != 0x7fffffff) D.arr_len[atomicAdd(D.arr_n, 1u) & 255u] = (uint32_t)st.len;   // an arrival, for the straggler check
+        if (st.L != INFINITY && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
     }
 }
 
