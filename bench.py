@@ -471,7 +471,7 @@ def main():
     total_gens = wd.sum_over_ranks(K, dev)
     ctx.check(ctx.lib.wa_acs_debug_counters(solver.h, dbg16.ctypes.data, 0))
     stragglers = {"handed_over": int(dbg16[9]), "finished_by_resume_blocks": int(dbg16[7]),
-                  "note": "ants that could no longer be among the depositing ranks left their walk launch at a block boundary and were finished "
+                  "note": "ants that could no longer be among the depositing ranks left their walk launch at one of the loop's checks and were finished "
                           "beside the next generation's ants on the previous generation's field (DESIGN 4e): every step taken, the two counts are equal"}
 
     prof = solver.profile_read()

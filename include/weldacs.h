@@ -203,7 +203,7 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
  * builds (-DWA_STAMPS / -DWA_ANT_TIME, tools/).
  * Stragglers (a single dense 6-neighbour search of at most 256 ants, DEV mode, alpha == 1, the first 64 generations of a search): only the
  * ranks o <= lambda - 1 deposit (ACSRank_3D.hpp:200) and only the shortest ant can become the best path (:263-264), so an ant that is
- * already longer than floor(lambda - 1) + 1 arrivals of its generation can change neither (about 110 of 256 ants per exploratory generation); at a 64-step block boundary it leaves the walk
+ * already longer than floor(lambda - 1) + 1 arrivals of its generation can change neither (about 140 of 256 ants per exploratory generation); at one of the loop's checks (every 64 nodes, every 16 once shorter ants have arrived) it leaves the walk
  * launch -- which lasts as long as its longest ant -- and a resume block of the NEXT generation's walk launch finishes the same walk on the
  * previous generation's field (intact until the next sweep), adding its arrival and its steps to its own generation's trace entry.  The
  * last generation of a wa_acs_run call hands nothing over, so agents[] and the trace are complete when the call's work is.  Results are

@@ -56,7 +56,7 @@ struct WaAcsDev {
     int32_t *dirty_list;           // [slot][n]
     int32_t *dcount;               // [slot][2]
     // stragglers (single-search dense solvers, colony <= 256; all null otherwise): an ant that can no longer be among the depositing ranks
-    // nor become the best path leaves its launch at a 64-step block boundary and is finished by a resume block of the NEXT generation's
+    // nor become the best path leaves its launch at one of the loop's checks (every 64 nodes; every 16 once it has seen shorter arrivals) and is finished by a resume block of the NEXT generation's
     // walk launch, on the previous generation's field (see k_walk_dev)
     uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (0xffffffff = none yet)
     uint32_t *arr_n;               // [1]
@@ -491,6 +491,17 @@ __device__ __forceinline__ void wa_walk_fast(const WaRun &R, const float *__rest
     st.cur = cur; st.len = len; st.step = (uint32_t)(len - 1); st.L = L;
 }
 
+#ifdef WA_STRAG_TIME
+__device__ unsigned long long wa_strag_t[128 * 8];
+__device__ __forceinline__ uint32_t wa_strag_arr(uint32_t *arr_n, int32_t cut_n, int32_t gen) {
+    const uint32_t i = atomicAdd(arr_n, 1u);
+    if ((int32_t)i == cut_n - 1 && gen < 128) wa_strag_t[gen * 8 + 1] = wall_clock64();
+    return i;
+}
+#define WA_ARR_IDX wa_strag_arr(D.arr_n, cut_n, gen)
+#else
+#define WA_ARR_IDX atomicAdd(D.arr_n, 1u)
+#endif
 #include "walk_loop_gfx950.hpp"   // wa_walk_fast_asm<LAZY>: the hand-scheduled general step
 
 // generic path: handles the spilled (global bitmap) tabu; same arithmetic, written plainly
@@ -787,7 +798,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-                if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
+                if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
             }
             return;
         }
@@ -839,7 +850,21 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             return false;
         }
         int32_t *pp = D.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
-        for (int32_t q = lane; q < st.len; q += 64) pp[q] = path[q];
+        // (through L2: the last, incomplete block was stored by this very wavefront a moment ago)
+        // 512 words per round: eight independent loads per lane, then eight stores (one memory round trip per round, not per 64 words)
+        for (int32_t q0 = 0; q0 < st.len; q0 += 512) {
+            int32_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t q = q0 + u * 64 + lane;
+                w[u] = q < st.len ? __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t q = q0 + u * 64 + lane;
+                if (q < st.len) pp[q] = w[u];
+            }
+        }
         if (lane == 0) {
             D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2] = ant;
             D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2 + 1] = st.len;
@@ -971,7 +996,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-        if (st.L != INFINITY && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
+        if (st.L != INFINITY && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
     }
 }
 
@@ -1128,6 +1153,9 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
+#ifdef WA_STRAG_TIME
+    if (threadIdx.x == 0 && gen < 128) atomicMax(&wa_strag_t[gen * 8 + 0], ~(unsigned long long)wall_clock64());
+#endif
     if (!SPARSE && ALPHA1 && D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
         // ---- resume block: a straggler of generation gen - 1 (walk_flags bit 5 allowed it to leave that launch) finishes its walk here,
         // on that generation's field, beside this generation's ants; only that generation's statistics hear of it
@@ -1141,6 +1169,9 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
                                                  walk_flags & 1, 0u, c->heur_slot, 0x7fffffff, D.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
+#ifdef WA_STRAG_TIME
+        if (threadIdx.x == 0 && gen < 128) atomicMax(&wa_strag_t[gen * 8 + 3], (unsigned long long)wall_clock64());
+#endif
         return;
     }
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
@@ -1162,6 +1193,14 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     if (cut_n < 1) cut_n = 1;
     wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot, cut_n, nullptr, 0, gen);
+#ifdef WA_STRAG_TIME
+    if (threadIdx.x == 0 && gen < 128) {
+        const bool arrived = D.antL[(int64_t)slot * D.max_colony + ant] != INFINITY;
+        atomicMax(&wa_strag_t[gen * 8 + (arrived ? 2 : 4)], (unsigned long long)wall_clock64());
+        atomicMax(&wa_strag_t[gen * 8 + (arrived ? 6 : 7)], ((unsigned long long)wall_clock64() << 16) | (unsigned long long)(D.antLen[(int64_t)slot * D.max_colony + ant] & 0xffff));
+        if (arrived) atomicAdd(&wa_strag_t[gen * 8 + 5], 1ULL);
+    }
+#endif
 #ifdef WA_ANT_TIME
     if (threadIdx.x == 0 && D.dbg) {
         if (slot == 0 && ant == 0) atomicAdd(&D.dbg[10], (unsigned long long)__builtin_readcyclecounter());

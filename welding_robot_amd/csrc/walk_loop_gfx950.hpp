@@ -357,8 +357,8 @@
     WA_SPAN_9                                                                                                     \
     "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
     "s_add_i32 m0, m0, 1\n"                                                                                       \
-    "s_and_b32 s46, m0, 63\n"                                                                                     \
-    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* block of 64 path words complete: event */    \
+    "s_and_b32 s46, m0, %[em]\n"                                  /* 63, or 15 once the straggler check has seen arrivals */ \
+    "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* block of 64 path words complete (or a check is due): event */ \
     "s_cmp_lg_u32 %[cur], %[end]\n"                                                                               \
     "s_cselect_b64 s[54:55], s[54:55], 0\n"                       /* arrived (:182): event */                     \
     WA_SPAN_10                                                                                                    \
@@ -447,14 +447,14 @@
 #define WA_ASM_STAMPS_DUMP ""
 #define WA_ASM_STAMPS_CLOBBER
 #endif
-// The straggler check (dense loops, one search per solver): at a block boundary an ant whose node count already exceeds that of %[cutn]
+// The straggler check (dense loops, one search per solver; TAG "f": at a block boundary, "p": inside a block, see the event handler): an ant whose node count already exceeds that of %[cutn]
 // arrivals of its generation cannot be among the depositing ranks nor become the best path any more; it leaves with code 5 and is
 // finished beside the next generation's ants (see k_walk_dev).  %[cut] = node counts of the arrivals so far (0xffffffff = none yet),
 // lane l looks at entries l, l+64, l+128, l+192; %[cutn] = 0x7fffffff switches the check off.  v86..v89 are the touch loads' registers
 // (nobody reads those): the loads in flight are drained first.
-#define WA_ASM_CUT                                                                                                \
+#define WA_ASM_CUT(TAG)                                                                                           \
     "s_cmp_eq_u32 %[cutn], 0x7fffffff\n"                                                                          \
-    "s_cbranch_scc1 Lwa_nocut%=\n"                                                                                \
+    "s_cbranch_scc1 Lwa_nocut_" TAG "%=\n"                                                                        \
     "s_waitcnt vmcnt(0)\n"                                                                                        \
     "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
     "global_load_dword v86, v94, %[cut] sc1\n"                                                                    \
@@ -467,13 +467,19 @@
     "v_cmp_gt_u32 vcc, s46, v87\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
     "v_cmp_gt_u32 vcc, s46, v88\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
     "v_cmp_gt_u32 vcc, s46, v89\n s_nop 4\n s_bcnt1_i32_b64 s59, vcc\n s_add_u32 s58, s58, s59\n"                \
+    "s_cmp_lg_u32 s58, 0\n"                                                                                       \
+    "s_cselect_b32 %[em], " WA_CUT_FINE_MASK ", %[em]\n"            /* shorter ants have arrived: from now on look every 16 steps */ \
     "s_cmp_ge_u32 s58, %[cutn]\n"                                                                                 \
-    "s_cbranch_scc0 Lwa_nocut%=\n"                                                                                \
+    "s_cbranch_scc0 Lwa_nocut_" TAG "%=\n"                                                                        \
     "s_mov_b32 %[code], 5\n"                                                                                      \
     "s_branch Lwa_out%=\n"                                                                                        \
-    "Lwa_nocut%=:\n"
+    "Lwa_nocut_" TAG "%=:\n"
+#define WA_ASM_NOCUT(TAG) ""
+#ifndef WA_CUT_FINE_MASK
+#define WA_CUT_FINE_MASK "15"
+#endif
 // everything behind the loop: the dead-end exit and the pending-event handler (a completed 64-word block and/or the arrival)
-#define WA_ASM_TAIL WA_ASM_TAIL_("")
+#define WA_ASM_TAIL WA_ASM_TAIL_(WA_ASM_NOCUT)
 #define WA_ASM_TAIL_(CUT)                                                                                         \
     "Lwa_dead%=:\n"                                                                                               \
     "s_mov_b32 %[code], 1\n"                                                                                      \
@@ -482,7 +488,13 @@
     WA_ASM_COUNT_EVENT                                                                                            \
     "s_mov_b32 %[code], 2\n"                                                                                      \
     "s_and_b32 s46, m0, 63\n"                                                                                     \
-    "s_cbranch_scc1 Lwa_out%=\n"                   /* no complete block: it is the arrival (:182-186) */          \
+    "s_cbranch_scc0 Lwa_full%=\n"                                                                                 \
+    "s_cmp_eq_u32 %[cur], %[end]\n"                                                                               \
+    "s_cbranch_scc1 Lwa_out%=\n"                   /* no complete block, at the end point: the arrival (:182-186) */ \
+    "s_mov_b32 %[code], 0\n"                      /* inside a block: a straggler check was due (%[em] = 15) */    \
+    CUT("p")                                                                                                      \
+    "s_branch Lwa_resume%=\n"                                                                                     \
+    "Lwa_full%=:\n"                                                                                               \
     "s_lshl_b32 s46, m0, 2\n"                      /* block [len-64, len) -> path[]: one coalesced 256-byte store */ \
     "v_lshlrev_b32 v94, 2, v64\n"                                                                                 \
     "v_add_u32 v94, s46, v94\n"                                                                                   \
@@ -494,7 +506,7 @@
     "s_add_i32 s46, m0, 64\n"                                                                                     \
     "s_cmp_gt_i32 s46, %[limit]\n"                                                                                \
     "s_cbranch_scc1 Lwa_out%=\n"                   /* the next block would pass the table-load / capacity limit: the caller's generic loop goes on */ \
-    CUT                                                                                                           \
+    CUT("f")                                                                                                      \
     "v_add_u32 v94, m0, v64\n"                     /* the next 64 draws: lane i <- draw of step len + i - 1 (wa_ctr_draw) */ \
     "v_add_u32 v94, -1, v94\n"                                                                                    \
     "s_mov_b32 s46, 0x9e3779b9\n"                                                                                 \
@@ -514,6 +526,7 @@
     "v_lshrrev_b32 v94, 1, v94\n"                                                                                 \
     "v_cvt_f32_u32 v94, v94\n"                                                                                    \
     "v_mul_f32 %[ub], 0x30000000, v94\n"           /* (float)r / 2^31 (:169) */                                   \
+    "Lwa_resume%=:\n"                                                                                             \
     "s_lshl_b64 s[54:55], 63, %[g8]\n"             /* the active mask back: evaluate the pending step again */    \
     "s_cmp_eq_u32 s47, 0\n"                                                                                       \
     "s_cbranch_scc1 Lwa_redo_a%=\n"                                                                               \
@@ -575,7 +588,7 @@
         WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
-        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), [em] "+s"(em) \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [cut] "s"(cut_list), [cutn] "s"(cut_n) \
         : WA_ASM_CLOBBERS);
@@ -595,7 +608,7 @@
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_REJ_EXITS                                                                                          \
         WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
-        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock) \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), [em] "+s"(em) \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [markb] "s"(mark), [cut] "s"(cut_list), [cutn] "s"(cut_n) \
         : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
@@ -630,7 +643,7 @@
         "Lwa_rare_d%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "3")                             \
         REJEXITS                                                                                                  \
         WA_ASM_TAIL                                                                                               \
-        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), \
+        : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), [em] "+s"(em), \
           [sio] "+v"(pd)                                                                                          \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b), [markb] "s"(mark) \
@@ -695,6 +708,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     }
     uint32_t pd = LAZY ? stamp[cur] : 1u;
     const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
+    int32_t em = 63;   // the loop raises an event whenever (node count & em) == 0: a completed block -- or, with 15, a straggler check inside one
     int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on, 5 straggler
     for (;;) {
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
