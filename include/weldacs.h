@@ -141,7 +141,7 @@ void wa_acs_destroy(wa_acs *s);
 /* device bytes a solver of this shape takes: per slot, per heuristic field (the pool holds one per distinct END point of a
  * batch, at least min(n_slots, 4)) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.
  * Nothing is allocated.  The drop-in ACS_Rank sizes the concurrent pair searches of a device from this and
- * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another).  A dense 6-neighbour solver with ONE slot and at most 256
+ * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another).  A dense solver (6 or 26 neighbours) with ONE slot and at most 256
  * ants additionally holds the straggler pools (see wa_acs_debug_counters): 2 x 256 paths of path_capacity words + 256 spill-bitmap rows
  * (0.6 GB at 128^3 with the default path capacity), not part of these figures. */
 int wa_acs_memory_estimate(const wa_grid *grid, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood, int32_t lazy,
@@ -201,9 +201,9 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
 /* diagnostic counters.  Product build: out16[9] = ants handed over as stragglers, out16[7] = stragglers finished by a resume block (the two
  * are equal after wa_acs_run returns), everything else zero; the cycle counters of the walk's inner loop only exist in the diagnostic
  * builds (-DWA_STAMPS / -DWA_ANT_TIME, tools/).
- * Stragglers (a single dense 6-neighbour search of at most 256 ants, DEV mode, alpha == 1, the first 64 generations of a search): only the
+ * Stragglers (a single dense search of at most 256 ants, 6 or 26 neighbours, DEV mode, alpha == 1, the first 64 generations of a search): only the
  * ranks o <= lambda - 1 deposit (ACSRank_3D.hpp:200) and only the shortest ant can become the best path (:263-264), so an ant that is
- * already longer than floor(lambda - 1) + 1 arrivals of its generation can change neither (about 140 of 256 ants per exploratory generation); at one of the loop's checks (every 64 nodes, every 16 once shorter ants have arrived) it leaves the walk
+ * already longer than floor(lambda - 1) + 1 arrivals of its generation (26 neighbours: whose L so far already exceeds theirs) can change neither (about 140 of 256 ants per exploratory generation); at one of the loop's checks (every 64 nodes, every 16 once shorter ants have arrived) it leaves the walk
  * launch -- which lasts as long as its longest ant -- and a resume block of the NEXT generation's walk launch finishes the same walk on the
  * previous generation's field (intact until the next sweep), adding its arrival and its steps to its own generation's trace entry.  The
  * last generation of a wa_acs_run call hands nothing over, so agents[] and the trace are complete when the call's work is.  Results are

@@ -319,10 +319,12 @@ def test_profile_can_stamp_the_sweep_launch_of_every_generation(ctx):
     s.close()
 
 
-def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
+@pytest.mark.parametrize("nb", [6, 26])
+def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch, nb):
     """A single dense search hands ants that can no longer matter to resume blocks of the next walk launch (include/weldacs.h,
     wa_acs_debug_counters).  With the mechanism on, off, and run generation by generation (where it never engages): the same trace --
-    steps and finite ants included --, the same ants in the last generation, the same field, all equal to the oracle."""
+    steps and finite ants included --, the same ants in the last generation, the same field, all equal to the oracle.  26 neighbours: the arrivals are compared by their L
+    (step lengths differ per move type), a resumed ant continues its in-order fp32 sum."""
     og = box_grid(48, 40, 44, occ_prob=0.1, seed=21)
     og.free[0] = og.free[-1] = 1
     n = 48 * 40 * 44
@@ -331,7 +333,7 @@ def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
     for mode in ("on", "off", "stepwise"):
         monkeypatch.setenv("WA_STRAGGLERS", "0" if mode == "off" else "1")
         dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
-        s = api.AcsSolver(ctx, dg, 1, 96)
+        s = api.AcsSolver(ctx, dg, 1, 96, neighbourhood=nb)
         p = api.default_params(max_iteration=14, predict=132.0, fixed_colony=96, rng_mode=api.RNG_DEV, seed=77)
         s.init_pheromone(1.0)
         ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 1))
@@ -353,7 +355,7 @@ def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
         res[mode] = (t["steps"].copy(), t["finite"].copy(), bits(t["bestL"]), bits(L), lens.copy(), bits(s.pheromone()))
         s.close()
         dg.close()
-    a = O.Acs(og)
+    a = O.Acs(og, nb=nb)
     tr = a.solve(0, n - 1, 14, 132.0, fixed_colony=96, mode=O.DEV, seed=77, stream=4)
     olens, oL = a.last_ants()
     want = (tr["steps"], tr["finite"], bits(tr["bestL"]), bits(oL), olens, bits(a.pheromone()))
@@ -362,14 +364,15 @@ def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch):
             assert np.array_equal(got, w), mode
 
 
+@pytest.mark.parametrize("nb", [6, 26])
 @pytest.mark.parametrize("chunks", [(2,), (3,), (2, 2, 1, 3), (5, 1, 4)])
-def test_straggler_hand_over_across_run_boundaries(ctx, chunks):
+def test_straggler_hand_over_across_run_boundaries(ctx, chunks, nb):
     """wa_acs_run in pieces: the last generation of every call hands nothing over, the others may; the search is the oracle's whatever the split."""
     og = box_grid(48, 40, 44, occ_prob=0.1, seed=21)
     og.free[0] = og.free[-1] = 1
     n, total = 48 * 40 * 44, sum(chunks)
     dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
-    s = api.AcsSolver(ctx, dg, 1, 96)
+    s = api.AcsSolver(ctx, dg, 1, 96, neighbourhood=nb)
     p = api.default_params(max_iteration=total, predict=132.0, fixed_colony=96, rng_mode=api.RNG_DEV, seed=78)
     s.init_pheromone(1.0)
     s.begin(p, 0, n - 1, streams=[2])
@@ -379,7 +382,7 @@ def test_straggler_hand_over_across_run_boundaries(ctx, chunks):
         out = np.zeros(16, np.uint64)
         ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
         assert int(out[9]) == int(out[7])                 # nothing is left over between calls
-    a = O.Acs(og)
+    a = O.Acs(og, nb=nb)
     tr = a.solve(0, n - 1, total, 132.0, fixed_colony=96, mode=O.DEV, seed=78, stream=2)
     t = s.trace()
     assert np.array_equal(t["steps"][:total], tr["steps"]) and np.array_equal(t["finite"][:total], tr["finite"])

@@ -300,8 +300,9 @@ def test_random_searches_down_the_other_code_paths(ctx, knobs, monkeypatch):
 
 
 # ------------------------------------------------------------------ stragglers on / off on random hand-over-heavy searches
+@pytest.mark.parametrize("nb", [6, 26])
 @pytest.mark.parametrize("trial", range(16))
-def test_random_searches_with_and_without_the_straggler_hand_over(ctx, trial, monkeypatch):
+def test_random_searches_with_and_without_the_straggler_hand_over(ctx, trial, monkeypatch, nb):
     """Which ants are handed over depends on timing; nothing observable may: trace (steps and finite ants included), the last
     generation's ants and the whole field with the mechanism on equal those with it off, and every straggler is finished."""
     from welding_robot_amd import synth
@@ -314,7 +315,7 @@ def test_random_searches_with_and_without_the_straggler_hand_over(ctx, trial, mo
     res, out = {}, np.zeros(16, np.uint64)
     for mode in ("1", "0"):
         monkeypatch.setenv("WA_STRAGGLERS", mode)
-        s = api.AcsSolver(ctx, grid, n_slots=1, max_colony=ants)
+        s = api.AcsSolver(ctx, grid, n_slots=1, max_colony=ants, neighbourhood=nb)
         p = api.default_params(max_iteration=gens, predict=3.0 * n, fixed_colony=ants, rng_mode=api.RNG_DEV, seed=1000 + trial)
         s.init_pheromone(1.0)
         ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 1))

@@ -61,7 +61,7 @@ struct WaAcsDev {
     uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (0xffffffff = none yet)
     uint32_t *arr_n;               // [1]
     int32_t *pool_n;               // [2]   stragglers of generation g in pool [g & 1]
-    int32_t *pool_rec;             // [2][WA_RESUME_MAX][2]  (ant, node count at the hand-over)
+    int32_t *pool_rec;             // [2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
     int32_t *pool_path;            // [2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
@@ -70,6 +70,7 @@ struct WaAcsDev {
 };
 
 #define WA_RESUME_MAX 256
+#define WA_POOL_REC 4
 
 // rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
 struct WaMaskRef {
@@ -866,8 +867,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             }
         }
         if (lane == 0) {
-            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2] = ant;
-            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * 2 + 1] = st.len;
+            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC] = ant;
+            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC + 1] = st.len;
             D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
             D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
 #ifndef WA_ANT_TIME
@@ -1161,7 +1162,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         // on that generation's field, beside this generation's ants; only that generation's statistics hear of it
         const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
         if (gen < 1 || r >= D.pool_n[pg] || r >= WA_RESUME_MAX) return;
-        const int32_t a = D.pool_rec[(pg * WA_RESUME_MAX + r) * 2], n0 = D.pool_rec[(pg * WA_RESUME_MAX + r) * 2 + 1];
+        const int32_t a = D.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC], n0 = D.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC + 1];
         WaAcsDev Dp = D;
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
@@ -2041,6 +2042,10 @@ __global__ __launch_bounds__(256) void k_apply_table26(WaAcsDev D, WaRun R)
     __shared__ float s_d[1024];
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    if (D.pool_n && blockIdx.x == 0) {   // stragglers: the next generation starts with no arrivals and an empty pool of its own (see k_apply_table)
+        D.arr_len[tid] = 0xffffffffu;
+        if (tid == 0) { *D.arr_n = 0; D.pool_n[D.ctl[slot].gen & 1] = 0; }
+    }
     if (blockIdx.x == 0) { wa_table26_lengths(D, R, slot, s_d); return; }
     if ((int32_t)blockIdx.x <= WA_TABLE26_BLOCKS) {
         const float dep_mine = (tid < 64 && tid < D.max_colony) ? D.depA[(int64_t)slot * D.max_colony + tid] : 0.f;
@@ -2094,25 +2099,53 @@ __device__ __forceinline__ int wa_walk_replay26(const float *__restrict__ T, int
 template <int MODE>
 __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant, int32_t start,
                                               int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t &rng_rs,
-                                              int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen)
+                                              int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen,
+                                              int32_t cut_n = 0x7fffffff, int32_t *res_words = nullptr, int32_t res_len = 0, float res_L = 0.f,
+                                              int32_t gen = 0, int32_t bits_row = -1)
 {
+    // Stragglers (see wa_walk_one / k_walk_dev): step lengths differ per move type here, so the arrivals publish the bits of
+    // their L (positive floats order like unsigned integers) and an ant compares the L it has accumulated so far -- a lower bound of
+    // its final L, every step adds a positive length -- against them.  res_words != nullptr: a resume block, which finishes the
+    // straggler whose path so far (res_len nodes, length res_L) stands in res_words and goes on writing there.
     const int lane = threadIdx.x;
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
-    int32_t *path = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    int32_t *path = res_words ? res_words : D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+    const int32_t *pfx = res_words ? res_words : D.bestpath + (int64_t)slot * D.path_cap;   // where the walked prefix stands
+    const bool cutting = MODE == 1 && cut_n != 0x7fffffff;
+    auto publish = [&](float Larr) {   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
+        if (cutting && lane == 0 && Larr != INFINITY)
+            __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], __float_as_uint(Larr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto finish = [&](float Lf, int32_t lenf) {   // agents[] of an ant -- or, for a resumed straggler, the rest of its generation's statistics
+        if (res_words) {
+            if (lane == 0) {
+                if (D.dbg) atomicAdd(&D.dbg[7], 1ULL);
+                if (gen < D.trace_cap) {
+                    const int64_t t = (int64_t)slot * D.trace_cap + gen;
+                    if (Lf != INFINITY) atomicAdd(&D.trFinite[t], 1);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(lenf - res_len));
+                }
+            }
+            return;
+        }
+        if (lane == 0) {
+            D.antL[(int64_t)slot * D.max_colony + ant] = Lf;
+            D.antLen[(int64_t)slot * D.max_colony + ant] = lenf;
+        }
+        publish(Lf);
+    };
     int32_t r_node = 0;
     float r_L = 0.f;
-    if (MODE == 1 && rlen > 1) {   // follow the best path while the ant's own draws take its edges
+    if (res_words) { r_node = res_len - 1; r_L = res_L; }
+    else if (MODE == 1 && rlen > 1) {   // follow the best path while the ant's own draws take its edges
         const float *RT = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
         const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
         const int what = wa_walk_replay26(RT, rlen, antkey, r_node);
         for (int32_t q = lane; q <= r_node; q += 64) path[q] = bpath[q];   // the walked prefix IS the best path's
         r_L = RT[(int64_t)r_node * WA_ROW26 + 28];                          // L on arrival at that node
         if (what != 3) {
-            if (lane == 0) {
-                D.antL[(int64_t)slot * D.max_colony + ant] = what == 2 ? r_L : INFINITY;
-                D.antLen[(int64_t)slot * D.max_colony + ant] = r_node + 1;
-            }
+            finish(what == 2 ? r_L : INFINITY, r_node + 1);
             return;
         }
     }
@@ -2120,17 +2153,17 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     T.tab = tab;
     T.mask = (1u << hash_log2) - 1u;
     T.shift = 32 - hash_log2;
-    T.bits = D.vbits + ((int64_t)slot * D.max_colony + ant) * D.vbits_words;
+    // (a resume block spills into a bitmap row of its own, behind the ants' rows)
+    T.bits = D.vbits + ((int64_t)slot * D.max_colony + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
     wa_tabu_clear(tab4, hash_log2);
     __builtin_amdgcn_wave_barrier();
-    if (r_node > 0) {   // deviated at best[r_node]: tabu set := the replayed prefix (distinct keys: concurrent CAS inserts)
-        const int32_t *bpath = D.bestpath + (int64_t)slot * D.path_cap;
+    if (r_node > 0) {   // deviated at best[r_node] (or resumed): tabu set := the walked prefix (distinct keys: concurrent CAS inserts)
         if (r_node + 1 <= spill_at) {
             for (int32_t q = lane; q <= r_node; q += 64) {
-                const int32_t key = bpath[q] & WaNbT<26>::IDM;
+                const int32_t key = pfx[q] & WaNbT<26>::IDM;
                 uint32_t h = ((uint32_t)key * 2654435761u) >> T.shift;
                 while (atomicCAS(&tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & T.mask;
             }
@@ -2151,7 +2184,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     uint32_t step = 0;
     float L = 0.f;
     if (r_node > 0) {
-        cur = D.bestpath[(int64_t)slot * D.path_cap + r_node] & WaNbT<26>::IDM;
+        cur = __builtin_amdgcn_readfirstlane(pfx[r_node] & WaNbT<26>::IDM);
         len = r_node + 1;
         step = (uint32_t)r_node;   // steps taken so far = draws consumed
         L = r_L;
@@ -2175,8 +2208,10 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         const uint32_t lane_off = (uint32_t)k * 4u;                                // this lane's edge inside a 104-byte record
         const int32_t last_vox = (int32_t)D.d.n - 1;
         int32_t pbuf = 0;                                                          // lane i = path word (len & ~63) + i
-        if (r_node > 0) { if (lane < (len & 63)) pbuf = D.bestpath[(int64_t)slot * D.path_cap + (len & ~63) + lane]; }
+        if (r_node > 0) { if (lane < (len & 63)) pbuf = pfx[(len & ~63) + lane]; }
         else pbuf = start;                                                         // (lane 0 is the only one that counts: len == 1)
+        asm volatile("" : "+v"(pbuf));   // the load above is waited for HERE: left pending, the compiler's waitcnt pass puts a vmcnt(0) in front of the
+                                         // loop's v_writelane into this register -- i.e. waits for the touch loads in every step
         float ublock = (float)wa_ctr_draw(antkey, (step & ~63u) + (uint32_t)lane) / 2147483648.0f;   // (float)rand()/(float)RAND_MAX (:169)
         // Vector memory returns in order and the compiler's waitcnt pass would wait for the youngest load it knows: the loop's six loads
         // per step are therefore inline statements with an exact wait -- the two record loads (needed at the top of the next step) are
@@ -2192,7 +2227,8 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         // tabu probe of neighbour k (:145): ends on the key (visited) or on an empty slot (not visited; where the key would go)
         uint32_t hs = ((uint32_t)cur * 2654435761u + hk) >> T.shift;
         int32_t tv = tab[hs];
-        bool alive = true;
+        bool alive = true, cut = false;
+        int32_t em = 63;   // the straggler check runs when (node count & em) == 0: at block boundaries, every 16 nodes once shorter ants have arrived
         while (len <= spill_at && len < (int32_t)D.path_cap) {
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(p), "+v"(h));                 // this step's records; the touch loads stay in flight
             const int32_t key = cur + dk;
@@ -2240,15 +2276,54 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             if ((step & 63u) == 0) ublock = (float)wa_ctr_draw(antkey, step + (uint32_t)lane) / 2147483648.0f;
             cur = next;
             if (next == end) { alive = false; break; }
+            if (cutting && (len & em) == 0) {   // arrivals of this generation with a smaller L than this ant has already
+                const uint32_t mine = __float_as_uint(L);
+                uint32_t e0 = __hip_atomic_load(&D.arr_len[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e1 = __hip_atomic_load(&D.arr_len[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e2 = __hip_atomic_load(&D.arr_len[lane + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e3 = __hip_atomic_load(&D.arr_len[lane + 192], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int32_t shorter = __popcll(__ballot(e0 < mine)) + __popcll(__ballot(e1 < mine)) + __popcll(__ballot(e2 < mine)) + __popcll(__ballot(e3 < mine));
+                if (shorter > 0) em = 15;
+                if (shorter >= cut_n) { cut = true; break; }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253");   // the last touches land before anything else runs
         if (lane < (len & 63)) path[(len & ~63) + lane] = pbuf;                    // the partial last block
         if (!alive) {
-            if (lane == 0) {
-                D.antL[(int64_t)slot * D.max_colony + ant] = L;
-                D.antLen[(int64_t)slot * D.max_colony + ant] = len;
-            }
+            finish(L, len);
             return;
+        }
+        if (cut) {
+            // a straggler: its path so far goes to a pool entry of its generation; agents[] says "not arrived, len nodes" (what the ranking
+            // sees); a resume block of the next walk launch finishes it.  Pool full: the ant walks on in the loop below, without the check
+            int32_t r = 0;
+            if (lane == 0) r = atomicAdd(&D.pool_n[gen & 1], 1);
+            r = __builtin_amdgcn_readfirstlane(r);
+            if (r < WA_RESUME_MAX) {
+                int32_t *pp = D.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
+                for (int32_t q0 = 0; q0 < len; q0 += 512) {   // (through L2: the last block was stored by this very wavefront a moment ago)
+                    int32_t w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int32_t q = q0 + u * 64 + lane;
+                        w[u] = q < len ? __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int32_t q = q0 + u * 64 + lane;
+                        if (q < len) pp[q] = w[u];
+                    }
+                }
+                if (lane == 0) {
+                    int32_t *rec = D.pool_rec + ((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC;
+                    rec[0] = ant; rec[1] = len; rec[2] = __float_as_int(L);
+                    D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
+                    D.antLen[(int64_t)slot * D.max_colony + ant] = len;
+                    if (D.dbg) atomicAdd(&D.dbg[9], 1ULL);
+                }
+                return;
+            }
+            if (lane == 0) atomicSub(&D.pool_n[gen & 1], 1);
         }
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();   // the hash is nearly full (the loop below moves the set to the bitmap: it reads path[] back) or path[]
@@ -2331,23 +2406,39 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         }
         __threadfence();
     }
-    if (lane == 0) {
-        D.antL[(int64_t)slot * D.max_colony + ant] = L;
-        D.antLen[(int64_t)slot * D.max_colony + ant] = len;
-    }
+    finish(L, len);
 }
 
-__global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
+// walk_flags bit 5: this generation may hand its stragglers over (the next launch of the call carries resume blocks, see k_walk_dev)
+__global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y, ant = blockIdx.x;
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
+    int32_t f = 0, b = 0, rs_unused = 0;
+    if (D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
+        // ---- resume block: a straggler of generation gen - 1 finishes its walk here, on that generation's field
+        const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
+        if (gen < 1 || r >= D.pool_n[pg] || r >= WA_RESUME_MAX) return;
+        const int32_t *rec = D.pool_rec + (pg * WA_RESUME_MAX + r) * WA_POOL_REC;
+        const int32_t a = rec[0], n0 = rec[1];
+        const float L0 = __int_as_float(rec[2]);
+        WaAcsDev Dp = D;
+        Dp.pher = const_cast<float *>(D.prev_pher);
+        const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
+        wa_walk_one26<1>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, 0, 0x7fffffff,
+                         D.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r);
+        return;
+    }
     if (ant >= colony || colony > D.max_colony) return;
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
-    int32_t f = 0, b = 0, rs_unused = 0;
     const int32_t rlen = (D.rtab && c->bestL != INFINITY) ? c->best_len : 0;
-    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen);
+    // an ant with a larger L than floor(lambda - 1) + 1 arrivals cannot be among the depositing ranks (:200) nor be the iteration's best
+    int32_t cut_n = 0x7fffffff;
+    if ((walk_flags & 32) && D.pool_n && R.alpha == 1) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
+    if (cut_n < 1) cut_n = 1;
+    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, cut_n, nullptr, 0, 0.f, gen);
 }
 
 __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
