@@ -58,7 +58,7 @@ struct WaAcsDev {
     // stragglers (single-search dense solvers, colony <= 256; all null otherwise): an ant that can no longer be among the depositing ranks
     // nor become the best path leaves its launch at one of the loop's checks (every 64 nodes; every 16 once it has seen shorter arrivals) and is finished by a resume block of the NEXT generation's
     // walk launch, on the previous generation's field (see k_walk_dev)
-    uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (0xffffffff = none yet)
+    uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (26 neighbours: the bits of their L; 0xffffffff = none yet)
     uint32_t *arr_n;               // [1]
     int32_t *pool_n;               // [2]   stragglers of generation g in pool [g & 1]
     int32_t *pool_rec;             // [2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
