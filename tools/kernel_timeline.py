@@ -12,7 +12,8 @@ for i in range(len(rows)-3):
         out.append((a[1]-a[0], b[0]-a[1], b[1]-b[0], c[0]-b[1], c[1]-c[0], d[0]-c[1]))
 import statistics as st
 def col(j, sel): return [o[j] for o in sel]
-for name, sel in (("exploratory (walk > 100 us)", [o for o in out if o[0]>100000]), ("converged (walk < 12 us)", [o for o in out if o[0]<12000])):
+# (the first triples of the trace are the search's first generations: bench.py's warm-up and timed generations follow each other)
+for name, sel in (("generations 0-19 of the search", out[:20]), ("generations 20-39", out[20:40]), ("exploratory (walk > 100 us)", [o for o in out if o[0]>100000]), ("converged (walk < 12 us)", [o for o in out if o[0]<12000])):
     if not sel: continue
     print("%s: %d generations" % (name, len(sel)))
     for j,lab in enumerate(("walk kernel","gap walk->fused","fused kernel","gap fused->apply","apply+table kernel","gap apply->next walk")):
