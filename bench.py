@@ -51,7 +51,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--grid", type=int, default=GRID_N)
     ap.add_argument("--ants", type=int, default=ANTS)
-    ap.add_argument("--cpu-gens", type=int, default=100, help="generations of the CPU baseline sample (the first of the same search, whatever --steps is)")
+    ap.add_argument("--cpu-gens", type=int, default=100, help="generations of the CPU baseline's second sample (window_100) when the timed region is shorter")
+    ap.add_argument("--cpu-gens-max", type=int, default=500, help="the CPU baseline runs the timed region's generations, at most this many")
     ap.add_argument("--cost-check-gens", type=int, default=None, help="generations the CPU port replays for cost_check (default: all K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10, help="stamp every n-th generation's launches with HIP events")
@@ -62,28 +63,35 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl, gpu_path, K):
-    """Reported baseline (never the target).  Same grid, same parameters, the first `cpu_gens` generations of the same search
-    (exploration and the start of convergence: ~5-10 s of the reference on one core); 1 thread like the reference.
+def _reference_run(O, og, n, wl, ants, gens, tmp):
+    """the reference's own loop (oracle/_ref/ref_harness) on `gens` generations of the search: its JSON line or None"""
+    p = subprocess.run([O.REF_BIN, "acs", "gridin=%s/grid.in" % tmp, "spt=0,0,0", "ept=%d,%d,%d" % (n - 1, n - 1, n - 1),
+                        "seed=%d" % wl["rng_seed"], "iters=%d" % gens, "predict=%s" % PREDICT, "fixed=%d" % ants, "out=%s/o.waf" % tmp],
+                       stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+    line = [l for l in p.stderr.splitlines() if l.startswith("{")]
+    return json.loads(line[-1]) if p.returncode == 0 and line else None
+
+
+def cpu_baseline(args, free, n, gpu_trace, wl, gpu_path, K, gpu_window_ms):
+    """Reported baseline (never the target).  Same grid, same parameters, THE SAME GENERATIONS as the timed region (0..K-1 of the same
+    search; capped at --cpu-gens-max), 1 thread like the reference.  `window_100`: the first 100 generations as a second sample when the
+    timed region is shorter (exploration and the start of convergence).
     cost_check: the DEV-mode port draws the same numbers as the GPU, so ALL K generations of the timed search are
     replayed on the CPU (66 s for 500) and the per-generation best cost, the iteration best, the step counts and the
     final best path must be equal bit for bit."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O  # cpu_baseline leg only
-    G = args.cpu_gens
+    G = min(K, args.cpu_gens_max)
     og = O.Grid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), free, 1.0, 0)
     sid, eid = og.resolve(np.zeros(3, np.float32)), og.resolve(np.full(3, n - 1, np.float32))
     out = {}
+    KC = K if args.cost_check_gens is None else min(K, args.cost_check_gens)
     a = O.Acs(og)
     t0 = time.time()
-    tr = a.solve(sid, eid, G, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
+    tr = a.solve(sid, eid, KC, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
     t_port = time.time() - t0
-    port_rate = G / t_port
-    KC = K if args.cost_check_gens is None else min(K, args.cost_check_gens)
-    if KC != G:   # the cost check replays exactly the timed generations (the baseline window above is its own run)
-        a = O.Acs(og)
-        tr = a.solve(sid, eid, KC, PREDICT, fixed_colony=args.ants, mode=O.DEV, seed=wl["rng_seed"], stream=wl["stream"])
+    port_rate = KC / t_port
     bit = lambda x: np.ascontiguousarray(x, np.float32).view(np.uint32)
     cost_equal = bool(np.array_equal(bit(tr["bestL"]), bit(gpu_trace["bestL"][:KC])) and
                       np.array_equal(bit(tr["iterbestL"]), bit(gpu_trace["iterbestL"][:KC])) and
@@ -93,24 +101,24 @@ def cpu_baseline(args, free, n, gpu_trace, gpu_first_ms, wl, gpu_path, K):
                          "gpu_best_cost": float(gpu_trace["bestL"][KC - 1]),
                          "bit_equal_trace": cost_equal, "best_path_equal": path_equal,
                          "checked": "best cost, iteration best and total steps of every generation; node ids of the final best path"}
-    sample = "generations 0..%d of the same %d^3 / %d-ant search; GPU took %.2f ms for the same window" % (
-        G - 1, n, args.ants, gpu_first_ms)
+    sample = "generations 0..%d of the same %d^3 / %d-ant search = %s; the GPU's timed region took %.2f ms for %d generations" % (
+        G - 1, n, args.ants, "the timed region's generations" if G == K else "the first %d of the timed region's %d" % (G, K), gpu_window_ms, K)
     if O.have_ref():
         tmp = "/tmp/weld_bench_%d" % os.getpid()
         os.makedirs(tmp, exist_ok=True)
         O.write_grid_in(og, tmp + "/grid.in")
-        p = subprocess.run([O.REF_BIN, "acs", "gridin=%s/grid.in" % tmp, "spt=0,0,0", "ept=%d,%d,%d" % (n - 1, n - 1, n - 1),
-                            "seed=%d" % wl["rng_seed"], "iters=%d" % G, "predict=%s" % PREDICT, "fixed=%d" % args.ants, "out=%s/o.waf" % tmp],
-                           stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
-        line = [l for l in p.stderr.splitlines() if l.startswith("{")]
-        if p.returncode == 0 and line:
-            j = json.loads(line[-1])
-            out["cpu_baseline"] = {"value": G / j["t_solve"], "unit": "generations/s", "cores": 1, "kind": "reference",
+        j = _reference_run(O, og, n, wl, args.ants, G, tmp)
+        if j is not None:
+            out["cpu_baseline"] = {"value": G / j["t_solve"], "unit": "generations/s", "cores": 1, "kind": "reference", "generations": [0, G - 1],
                                    "sample": sample + "; reference phase split walk %.0f%% evaporate %.0f%% deposit %.0f%%" % (
                                        100 * j["t_walk"] / j["t_solve"], 100 * j["t_evap"] / j["t_solve"], 100 * j["t_dep"] / j["t_solve"]),
-                                   "init_s": j["t_init"], "port_value": port_rate}
+                                   "init_s": j["t_init"], "port_value": port_rate, "port_generations": [0, KC - 1]}
+            if G < 100 and args.cpu_gens > G:   # a second, longer sample of the same search
+                j2 = _reference_run(O, og, n, wl, args.ants, args.cpu_gens, tmp)
+                if j2 is not None:
+                    out["cpu_baseline"]["window_%d" % args.cpu_gens] = {"value": args.cpu_gens / j2["t_solve"], "generations": [0, args.cpu_gens - 1], "unit": "generations/s"}
             return out
-    out["cpu_baseline"] = {"value": port_rate, "unit": "generations/s", "cores": 1, "kind": "port", "sample": sample}
+    out["cpu_baseline"] = {"value": port_rate, "unit": "generations/s", "cores": 1, "kind": "port", "generations": [0, KC - 1], "sample": sample}
     return out
 
 
@@ -251,44 +259,85 @@ def live_traffic(n, ants, timeout_s=90):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def multi_start_extra(ctx, grid, params, ids, n, ants, problems=8, gens=100):
-    """BASELINE config 4's workload on ONE GPU: `problems` independent searches of the same grid (different DEV streams: a multi-start
-    batch) advance together, one launch per kernel and generation for all of them.  A lone search leaves the chip almost empty (256
-    wavefronts); eight fill 2 048 wave slots for the same walk latency, and their sweep streams 8 x 100 MB per launch -- past the 256 MiB
-    Infinity Cache, so `in_loop_frac` here is an HBM figure.  The same batch with lazy evaporation (wa_acs_create_lazy: never-deposited
-    voxels are not swept) stands beside it and must give the same histories.  Outside `value`."""
+def multi_start_run(ctx, grid, ids, n, ants, problems, groups, gens, lazy, warm=5, seed=4242):
+    """`problems` independent searches of the same grid (different DEV streams) in the slots of one solver, split into `groups`
+    pipelined groups (0: the library's rule; wa_acs_set_pipeline): problem-generations/s over generations warm..gens-1, per-launch
+    kernel times (sampled every 10th generation), the in-loop sweep's fraction of the HBM peak, the histories."""
     import numpy as np
     from welding_robot_amd import api
+    s = api.AcsSolver(ctx, grid, n_slots=problems, max_colony=ants, lazy=lazy)
+    s.set_pipeline(groups)
+    p = api.default_params(max_iteration=gens, predict=PREDICT * ants / ANTS, fixed_colony=ants, rng_mode=api.RNG_DEV, seed=seed)
+    s.init_pheromone(1.0)
+    s.begin(p, [ids[0]] * problems, [ids[1]] * problems, streams=list(range(100, 100 + problems)))
+    s.run(warm)                                                       # warm-up generations of the same searches
+    s.sync()
+    s.profile(True, 10)
+    t0 = time.perf_counter()
+    s.run(gens - warm)
+    t_enq = time.perf_counter() - t0                                  # the host's share: wa_acs_run returns when everything is enqueued
+    s.sync()
+    dt = time.perf_counter() - t0
+    pr = s.profile_read()
+    costs, _ = s.results(problems)
+    hist = np.stack([np.ascontiguousarray(s.trace(q)["bestL"], np.float32).view(np.uint32) for q in range(problems)])
+    steps = np.stack([s.trace(q)["steps"] for q in range(problems)])
+    used = s.pipeline_groups()
+    s.close()
+    per = {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()}
+    fused_ms = per["evaporate"]
+    out = {"kind": "lazy" if lazy else "dense", "problems": problems, "groups": used,
+           "problem_generations_per_s": problems * (gens - warm) / dt, "ms_per_generation_of_all": dt * 1e3 / (gens - warm),
+           "host_enqueue_ms_per_generation_of_all": t_enq * 1e3 / (gens - warm), "kernel_ms_per_launch": per,
+           "slots_per_launch": problems / used,
+           "in_loop_sweep_frac": None if lazy or fused_ms <= 0 else (problems / used) * 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out, hist, steps, costs
+
+
+def multi_start_extra(ctx, grid, params, ids, n, ants, problems=8, gens=100):
+    """BASELINE config 4's workload on ONE GPU: `problems` independent searches of the same grid (different DEV streams: a multi-start
+    batch) in the slots of one solver.  A lone search leaves the chip almost empty (256 wavefronts); eight fill 2 048 wave slots, and their
+    sweeps stream 8 x 100 MB per generation -- past the 256 MiB Infinity Cache, so `in_loop_frac` (one launch for all eight: groups = 1)
+    is an HBM figure.  `pipelined`: the same batch as the library runs it by default -- two groups of slots on streams of their own, one
+    group's sweep under the other's walk (wa_acs_set_pipeline) -- and the same with lazy evaporation; all histories must be equal.
+    Outside `value`."""
+    import numpy as np
     out = {"workload": "%d independent %d^3 / %d-ant searches on one GPU, generations 5..%d of each" % (problems, n, ants, gens - 1)}
-    hist = {}
-    for lazy in (False, True):
-        s = api.AcsSolver(ctx, grid, n_slots=problems, max_colony=ants, lazy=lazy)
-        p = params(gens, 4242)
-        streams = list(range(100, 100 + problems))
-        s.init_pheromone(1.0)
-        s.begin(p, [ids[0]] * problems, [ids[1]] * problems, streams=streams)
-        s.run(5)                                                      # warm-up generations of the same searches
-        s.sync()
-        s.profile(True, 10)
-        t0 = time.perf_counter()
-        s.run(gens - 5)
-        s.sync()
-        dt = time.perf_counter() - t0
-        pr = s.profile_read()
-        costs, _ = s.results(problems)
-        hist[lazy] = np.stack([np.ascontiguousarray(s.trace(q)["bestL"], np.float32).view(np.uint32) for q in range(problems)])
-        fused_ms = pr["evaporate"]["ms"] / max(pr["evaporate"]["launches"], 1)
-        s.close()
-        key = "lazy_" if lazy else ""
-        out[key + "problem_generations_per_s"] = problems * (gens - 5) / dt
-        out[key + "kernel_ms_per_generation"] = {k: v["ms"] / max(v["launches"], 1) for k, v in pr.items()}
-        if not lazy:
-            out["ms_per_generation_of_all"] = dt * 1e3 / (gens - 5)
-            out["in_loop_frac"] = problems * 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None
-            out["bytes_per_launch"] = problems * 48.0 * n ** 3
-            out["best_costs"] = [float(c) for c in costs]
-    out["lazy_identical_histories"] = bool(np.array_equal(hist[False], hist[True]))
+    one, h1, s1, costs = multi_start_run(ctx, grid, ids, n, ants, problems, 1, gens, False)
+    pip, h2, s2, _ = multi_start_run(ctx, grid, ids, n, ants, problems, 0, gens, False)
+    lz1, h3, s3, _ = multi_start_run(ctx, grid, ids, n, ants, problems, 1, gens, True)
+    lzp, h4, s4, _ = multi_start_run(ctx, grid, ids, n, ants, problems, 0, gens, True)
+    out["one_stream"] = one
+    out["pipelined"] = pip
+    out["lazy_one_stream"] = lz1
+    out["lazy_pipelined"] = lzp
+    out["problem_generations_per_s"] = pip["problem_generations_per_s"]
+    out["lazy_problem_generations_per_s"] = lzp["problem_generations_per_s"]
+    out["in_loop_frac"] = one["in_loop_sweep_frac"]
+    out["bytes_per_launch"] = problems * 48.0 * n ** 3
+    out["best_costs"] = [float(c) for c in costs]
+    out["pipelined_identical_histories"] = bool(np.array_equal(h1, h2) and np.array_equal(s1, s2))
+    out["lazy_identical_histories"] = bool(np.array_equal(h1, h3) and np.array_equal(h1, h4) and np.array_equal(s1, s3) and np.array_equal(s1, s4))
     return out
+
+
+def multi_start_curve_extra(ctx, grid, ids, n, ants, gens=60):
+    """Problems-per-GPU curve: P = 1 .. 32 independent searches per solver, dense and lazy, on one stream and as the library pipelines them
+    by rule; problem-generations/s over generations 5..gens-1, per-launch kernel times, in-loop sweep fraction.  Outside `value`; bounded."""
+    import numpy as np
+    rows = []
+    for lazy in (False, True):
+        for P in (1, 2, 4, 8, 16, 32):
+            ref = None
+            for G in (1, 0):
+                r, h, st, _ = multi_start_run(ctx, grid, ids, n, ants, P, G, gens, lazy)
+                if ref is None:
+                    ref = (h, st)
+                elif r["groups"] == 1:
+                    continue                                          # the rule keeps this batch on one stream: already measured
+                r["identical_to_one_stream"] = bool(np.array_equal(h, ref[0]) and np.array_equal(st, ref[1]))
+                rows.append(r)
+    return {"workload": "%d^3 / %d-ant multi-start batches, generations 5..%d" % (n, ants, gens - 1), "rows": rows}
 
 
 def c5_full_extra(ctx):
@@ -542,38 +591,35 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": fused_ms, "sampled_launches": fused["launches"],
-                         "note": "at 128^3 both 48 MiB buffers sit in the 256 MiB Infinity Cache: frac is an on-die figure; sweep_alone.frac_256 is the HBM one",
+                         "frac_hbm": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None,
+                         "note": "at 128^3 both 48 MiB buffers sit in the 256 MiB Infinity Cache: frac is an on-die figure; frac_hbm (= sweep_alone.frac_256: the same sweep "
+                                 "on a 256^3 field, 805 MB per launch, non-temporal loads and stores by the library's rule) is the HBM one; multi_start.in_loop_frac is the "
+                                 "in-loop HBM figure (eight 128^3 fields per launch)",
                          "sweep_alone": {"kernel": "k_evaporate, launched alone %d times after the timed region" % r128["launches"],
                                          "frac_128": r128["achieved"] / HBM_PEAK_GBS, "avg_launch_ms_128": r128["avg_launch_ms"], "traffic_128": traffic_alone,
                                          "frac_256": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None, "traffic_256": traffic_256, "sweep_256": r256},
                          "end_to_end_frac": alg_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBS},
-            "kernel_ms_per_generation": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
+            "kernel_ms_sampled": dict({k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
+                                      generations=[g for g in range(K) if g % args.profile_every == 0],
+                                      note="average over the STAMPED generations only (every %d-th of the timed region: hipEventRecord around each launch, which "
+                                           "costs the stream ~8 us per stamp, so the sum exceeds ms_per_step); the unperturbed per-kernel times of this command are "
+                                           "the rocprofv3 kernel stats under profiles/" % args.profile_every),
             "stragglers": stragglers, "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
             "device": ctx.device_name,
         }
-        if world == 1 and not args.no_cpu:
-            G = args.cpu_gens
-            # GPU time for the same first-G window, measured on a fresh identical search
-            solver.profile(False, 1)
-            solver.init_pheromone(1.0)
-            solver.begin(params(max(K, G), wl["rng_seed"]), ids[0], ids[1], streams=[wl["stream"]])
-            ctx.sync()
-            t1 = time.perf_counter()
-            solver.run(G)
-            solver.sync()
-            gpu_first_ms = (time.perf_counter() - t1) * 1e3
         if world == 1:
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
             out["full_run"] = full_run_extra(solver, params, ids, wl, n)
             out["multi_start"] = multi_start_extra(ctx, grid, params, ids, n, args.ants)
+            out["multi_start_curve"] = multi_start_curve_extra(ctx, grid, ids, n, args.ants)
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
             solver.close()
             out["c5_full"] = c5_full_extra(ctx)
         if world == 1 and not args.no_cpu:
             # the CPU leg comes last (the extras before it are host-paced: 0.52-0.84 s for the C5 extra from box to box, whatever runs in front)
-            out.update(cpu_baseline(args, free, n, trace, gpu_first_ms, wl, path, K))
+            out.update(cpu_baseline(args, free, n, trace, wl, path, K, elapsed * 1e3))
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -141,11 +141,16 @@ void wa_acs_destroy(wa_acs *s);
 /* device bytes a solver of this shape takes: per slot, per heuristic field (the pool holds one per distinct END point of a
  * batch, at least min(n_slots, 4)) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.
  * Nothing is allocated.  The drop-in ACS_Rank sizes the concurrent pair searches of a device from this and
- * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another).  A dense solver (6 or 26 neighbours) with ONE slot and at most 256
- * ants additionally holds the straggler pools (see wa_acs_debug_counters): 2 x 256 paths of path_capacity words + 256 spill-bitmap rows
- * (0.6 GB at 128^3 with the default path capacity), not part of these figures. */
+ * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another).  The straggler pools of small dense solvers come on top:
+ * wa_acs_straggler_pool_bytes. */
 int wa_acs_memory_estimate(const wa_grid *grid, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood, int32_t lazy,
                            int64_t *bytes_per_slot, int64_t *bytes_per_heuristic_field, int64_t *bytes_fixed);
+/* A dense solver (6 or 26 neighbours) of at most 256 ants and at most 16 slots (WA_STRAGGLER_SLOTS) additionally holds, PER SLOT, the
+ * arrival list and the straggler pools (see wa_acs_debug_counters): 2 x 256 paths of path_capacity words + 256 spill-bitmap rows
+ * (0.6 GB per slot at 128^3 with the default path capacity).  *bytes = what a solver of this shape holds in total, 0 when it
+ * gets none (lazy, larger colonies, more slots, WA_STRAGGLERS=0). */
+int wa_acs_straggler_pool_bytes(const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood,
+                                int32_t lazy, int64_t *bytes);
 /* initFromGridMap :343-408: in-bounds edges pheromone_0, out-of-bounds edges 0. slot<0: all */
 int wa_acs_init_pheromone(wa_acs *s, int32_t slot, float pheromone_0);
 /* reset() :307-315: every edge pheromone_0 */
@@ -162,6 +167,15 @@ int wa_acs_begin(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
                  const int64_t *end_ids, const uint32_t *streams);
 int wa_acs_run(wa_acs *s, int32_t n_generations);
 int wa_acs_sync(wa_acs *s);
+/* Pipelined groups.  The searches of a batch are independent (ACSRank_3D.hpp:472-499 is a loop over searches with a pheromone
+ * reset in between, :481): wa_acs_run splits the active slots into `groups` contiguous groups that advance on HIP streams of
+ * their own, so that one group's HBM-bound evaporation sweep (:268-272) runs under another group's latency-bound walk
+ * (:252-261).  The groups are forked from the context's stream when wa_acs_run starts and joined into it before it returns,
+ * so everything enqueued on the context afterwards is ordered behind all of them.  Every slot's own launch sequence is the
+ * single-stream one: results do not depend on the split.  groups = 0: by rule (WA_PIPE_GROUPS, read at creation, overrides
+ * the rule); 1: everything on the context's stream.  wa_acs_pipeline_info: the groups the last wa_acs_run used. */
+int wa_acs_set_pipeline(wa_acs *s, int32_t groups);
+int wa_acs_pipeline_info(const wa_acs *s, int32_t *groups_last_run);
 /* begin + run(max_iteration) + sync */
 int wa_acs_solve(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const int64_t *start_ids,
                  const int64_t *end_ids, const uint32_t *streams);

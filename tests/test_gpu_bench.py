@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_json_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "4", "--cpu-gens", "3"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "4", "--cpu-gens", "100"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -32,6 +32,7 @@ def test_bench_json_contract():
     # the timed region; the sweep kernel launched alone (>= 64 stamped launches, at the BASELINE size and past the Infinity
     # Cache) stands beside it; measured traffic (committed PMC passes) is within 2 % of the algorithmic bytes where it is quoted
     assert rf["kernel"].startswith("k_evap_rank_mark") and rf["sampled_launches"] >= 32
+    assert rf["frac_hbm"] == rf["sweep_alone"]["frac_256"] and rf["frac_hbm"] > 0.7   # the HBM-resident sweep (non-temporal by rule past the Infinity Cache)
     sa = rf["sweep_alone"]
     assert sa["kernel"].startswith("k_evaporate") and 0.3 < sa["frac_256"] < 1.0 and sa["frac_128"] >= rf["frac"] * 0.95
     assert sa["sweep_256"]["algorithmic_bytes_per_launch"] == 48.0 * 256 ** 3
@@ -43,11 +44,22 @@ def test_bench_json_contract():
     assert ms["problem_generations_per_s"] > 15000 and 0.4 < ms["in_loop_frac"] < 1.0
     assert ms["bytes_per_launch"] == 8 * 48.0 * 128 ** 3 and all(c == 378.0 for c in ms["best_costs"])
     assert ms["lazy_identical_histories"] is True and ms["lazy_problem_generations_per_s"] > ms["problem_generations_per_s"]
+    # the batch as the library pipelines it by rule (two groups of slots on streams of their own) against one stream: same histories, not slower
+    assert ms["pipelined"]["groups"] == 2 and ms["one_stream"]["groups"] == 1 and ms["pipelined_identical_histories"] is True
+    assert ms["pipelined"]["problem_generations_per_s"] > 0.97 * ms["one_stream"]["problem_generations_per_s"]
+    mc = d["multi_start_curve"]["rows"]   # problems-per-GPU curve: P = 1..32, dense and lazy, one stream and pipelined
+    assert {(r["kind"], r["problems"]) for r in mc} == {(k, P) for k in ("dense", "lazy") for P in (1, 2, 4, 8, 16, 32)}
+    assert all(r["identical_to_one_stream"] for r in mc if r["groups"] > 1) and any(r["groups"] == 2 for r in mc)
+    ks = d["kernel_ms_sampled"]
+    assert ks["generations"] == [0, 10, 20, 30, 40, 50] and ks["walk"] > 0
     fr, c5 = d["full_run"], d["c5_full"]
     assert fr["generations"] == 500 and fr["best_cost"] == 378.0 and fr["generations_per_s"] > d["value"]
     assert c5["all_reached"] is True and c5["slots_by_rule"] * c5["batches"] >= 2016 and c5["t_pairs_s"] < 10
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["generations"] == [0, 59]                      # the CPU baseline is timed on the timed region's own generations
+    if cb["kind"] == "reference":
+        assert cb["window_100"]["generations"] == [0, 99] and cb["window_100"]["value"] > 0
     cc = d["cost_check"]   # all 60 timed generations replayed by the CPU port: history and final best path equal
     assert cc["bit_equal_trace"] is True and cc["generations"] == 60 and cc["best_path_equal"] is True
     sg = d["stragglers"]   # the hand-over engaged in the timed region and every straggler was finished

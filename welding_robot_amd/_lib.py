@@ -55,6 +55,7 @@ SYMBOLS = {
     "wa_acs_create_lazy": (C.c_int, [_V, _V, _I, _I, _I64, C.POINTER(_V)]),
     "wa_acs_destroy": (None, [_V]),
     "wa_acs_memory_estimate": (C.c_int, [_V, _I, _I64, _I, _I, _P, _P, _P]),
+    "wa_acs_straggler_pool_bytes": (C.c_int, [_V, _I, _I, _I64, _I, _I, _P]),
     "wa_acs_init_pheromone": (C.c_int, [_V, _I, _F]),
     "wa_acs_reset_pheromone": (C.c_int, [_V, _I, _F]),
     "wa_acs_srand": (C.c_int, [_V, C.c_uint32]),
@@ -62,6 +63,8 @@ SYMBOLS = {
     "wa_acs_begin": (C.c_int, [_V, C.POINTER(AcsParams), _I, _P, _P, _P]),
     "wa_acs_run": (C.c_int, [_V, _I]),
     "wa_acs_sync": (C.c_int, [_V]),
+    "wa_acs_set_pipeline": (C.c_int, [_V, _I]),
+    "wa_acs_pipeline_info": (C.c_int, [_V, _P]),
     "wa_acs_solve": (C.c_int, [_V, C.POINTER(AcsParams), _I, _P, _P, _P]),
     "wa_acs_result": (C.c_int, [_V, _I, _P, _P, _P, _P, _I64]),
     "wa_acs_result_batch": (C.c_int, [_V, _I, _P, _P, _P, _I64]),

@@ -202,6 +202,15 @@ class AcsSolver:
     def sync(self):
         self.ctx.check(self.ctx.lib.wa_acs_sync(self.h))
 
+    def set_pipeline(self, groups):
+        """groups of slots that advance on streams of their own inside run() (0: by rule, 1: one stream)"""
+        self.ctx.check(self.ctx.lib.wa_acs_set_pipeline(self.h, groups))
+
+    def pipeline_groups(self):
+        g = C.c_int32()
+        self.ctx.check(self.ctx.lib.wa_acs_pipeline_info(self.h, C.byref(g)))
+        return g.value
+
     def solve(self, params, starts, ends, streams=None):
         starts, ends, streams = self._arrs(starts, ends, streams)
         self.n_active = len(starts)
@@ -287,6 +296,13 @@ def memory_estimate(grid, max_colony, path_capacity=0, neighbourhood=6, lazy=Fal
     grid.ctx.check(grid.ctx.lib.wa_acs_memory_estimate(grid.h, max_colony, path_capacity, neighbourhood, 1 if lazy else 0,
                                                        C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def straggler_pool_bytes(grid, n_slots, max_colony, path_capacity=0, neighbourhood=6, lazy=False):
+    """bytes of arrival lists + straggler pools a solver of this shape holds (0 when it gets none)"""
+    b = C.c_int64()
+    grid.ctx.check(grid.ctx.lib.wa_acs_straggler_pool_bytes(grid.h, n_slots, max_colony, path_capacity, neighbourhood, 1 if lazy else 0, C.byref(b)))
+    return b.value
 
 
 def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True):

@@ -32,7 +32,7 @@ struct WaAcsDev {
     int32_t *perm;                 // [slot][max_colony]   rank o-1 -> ant
     float *depA;                   // [slot][max_colony]   (lambda-o)*Q/L of rank o
     float *sortk;                  // [slot][2*max_colony] REF introsort scratch (key, tag records)
-    uint32_t *vbits;               // [slot][max_colony][vbits_words] spill tabu bitmap (all zero at rest)
+    uint32_t *vbits;               // [slot][vbits_rows][vbits_words] spill tabu bitmap (all zero at rest)
     WaSlotCtl *ctl;                // [slot]
     WaGlibcRand *rng;              // REF stream (one per solver, like the process-global rand())
     unsigned long long *dbg;       // [16] diagnostic cycle counters (only written by -DWA_STAMPS builds)
@@ -58,19 +58,36 @@ struct WaAcsDev {
     // stragglers (single-search dense solvers, colony <= 256; all null otherwise): an ant that can no longer be among the depositing ranks
     // nor become the best path leaves its launch at one of the loop's checks (every 64 nodes; every 16 once it has seen shorter arrivals) and is finished by a resume block of the NEXT generation's
     // walk launch, on the previous generation's field (see k_walk_dev)
-    uint32_t *arr_len;             // [256] node counts of the running generation's arrivals (26 neighbours: the bits of their L; 0xffffffff = none yet)
-    uint32_t *arr_n;               // [1]
-    int32_t *pool_n;               // [2]   stragglers of generation g in pool [g & 1]
-    int32_t *pool_rec;             // [2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
-    int32_t *pool_path;            // [2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
+    uint32_t *arr_len;             // [slot][256] node counts of the running generation's arrivals (26 neighbours: the bits of their L; 0xffffffff = none yet)
+    uint32_t *arr_n;               // [slot]
+    int32_t *pool_n;               // [slot][2]   stragglers of generation g in pool [g & 1]
+    int32_t *pool_rec;             // [slot][2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
+    int32_t *pool_path;            // [slot][2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
+    int32_t vbits_rows;            // bitmap rows per slot: max_colony (+ WA_RESUME_MAX rows of the resume blocks when the solver has straggler pools)
 };
 
 #define WA_RESUME_MAX 256
 #define WA_POOL_REC 4
+
+// the arrival list and the straggler pools of ONE slot (every search of a launch hands its own stragglers over)
+struct WaStrag {
+    uint32_t *arr_len, *arr_n;
+    int32_t *pool_n, *pool_rec, *pool_path;
+};
+__device__ __forceinline__ WaStrag wa_strag_of(const WaAcsDev &D, int32_t slot)
+{
+    WaStrag g;
+    g.arr_len = D.arr_len + (int64_t)slot * 256;
+    g.arr_n = D.arr_n + slot;
+    g.pool_n = D.pool_n + (int64_t)slot * 2;
+    g.pool_rec = D.pool_rec + (int64_t)slot * 2 * WA_RESUME_MAX * WA_POOL_REC;
+    g.pool_path = D.pool_path + (int64_t)slot * 2 * WA_RESUME_MAX * D.path_cap;
+    return g;
+}
 
 // rank masks of one slot: u64 per edge, or one byte per edge for small colonies (8x less memory: 805 -> 101 MB per slot at 256^3)
 struct WaMaskRef {
@@ -191,10 +208,11 @@ __global__ void k_begin(WaAcsDev D, WaRun R, int32_t n_problems, const long long
     c.flags = 0;
     wa_next_params(c, R, 0);
     D.ctl[slot] = c;
-    if (D.pool_n && slot == 0) {
-        D.pool_n[0] = D.pool_n[1] = 0;
-        *D.arr_n = 0;
-        for (int i = 0; i < 256; i++) D.arr_len[i] = 0xffffffffu;
+    if (D.pool_n) {
+        const WaStrag sg = wa_strag_of(D, slot);
+        sg.pool_n[0] = sg.pool_n[1] = 0;
+        *sg.arr_n = 0;
+        for (int i = 0; i < 256; i++) sg.arr_len[i] = 0xffffffffu;
     }
 }
 
@@ -499,9 +517,9 @@ __device__ __forceinline__ uint32_t wa_strag_arr(uint32_t *arr_n, int32_t cut_n,
     if ((int32_t)i == cut_n - 1 && gen < 128) wa_strag_t[gen * 8 + 1] = wall_clock64();
     return i;
 }
-#define WA_ARR_IDX wa_strag_arr(D.arr_n, cut_n, gen)
+#define WA_ARR_IDX wa_strag_arr(sg.arr_n, cut_n, gen)
 #else
-#define WA_ARR_IDX atomicAdd(D.arr_n, 1u)
+#define WA_ARR_IDX atomicAdd(sg.arr_n, 1u)
 #endif
 #include "walk_loop_gfx950.hpp"   // wa_walk_fast_asm<LAZY>: the hand-scheduled general step
 
@@ -739,6 +757,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     // walk continues behind its res_len nodes (D.pher is then that generation's field, rlen 0, no rejoin watch) and only its statistics
     // are delivered (the ant's slot in agents[] belongs to the running generation's ant by now)
     const int lane = threadIdx.x;
+    const WaStrag sg = wa_strag_of(D, slot);   // (only dereferenced where D.pool_n is set: cut_n / res_words say so)
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)heur_slot * D.pher_stride;   // (the caller read it with the rest of the control block)
     const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
@@ -799,7 +818,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-                if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
+                if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&sg.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
             }
             return;
         }
@@ -813,7 +832,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     T.mask = (1u << hash_log2) - 1u;
     T.shift = 32 - hash_log2;
     // (a resume block spills into a bitmap row of its own, behind the ants' rows: the ant's row belongs to the running generation's ant)
-    T.bits = D.vbits + ((int64_t)slot * D.max_colony + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
+    T.bits = D.vbits + ((int64_t)slot * D.vbits_rows + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
 
@@ -844,13 +863,13 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     // the generation's statistics.  False when the pool is full: the ant walks on without the check.
     auto hand_over = [&]() -> bool {
         int32_t r = 0;
-        if (lane == 0) r = atomicAdd(&D.pool_n[gen & 1], 1);
+        if (lane == 0) r = atomicAdd(&sg.pool_n[gen & 1], 1);
         r = __builtin_amdgcn_readfirstlane(r);
         if (r >= WA_RESUME_MAX) {
-            if (lane == 0) atomicSub(&D.pool_n[gen & 1], 1);
+            if (lane == 0) atomicSub(&sg.pool_n[gen & 1], 1);
             return false;
         }
-        int32_t *pp = D.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
+        int32_t *pp = sg.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
         // (through L2: the last, incomplete block was stored by this very wavefront a moment ago)
         // 512 words per round: eight independent loads per lane, then eight stores (one memory round trip per round, not per 64 words)
         for (int32_t q0 = 0; q0 < st.len; q0 += 512) {
@@ -867,8 +886,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             }
         }
         if (lane == 0) {
-            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC] = ant;
-            D.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC + 1] = st.len;
+            sg.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC] = ant;
+            sg.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC + 1] = st.len;
             D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
             D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
 #ifndef WA_ANT_TIME
@@ -900,7 +919,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         for (;;) {
             wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                              D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold,
-                                             SPARSE ? nullptr : D.arr_len, cut_n);
+                                             SPARSE ? nullptr : sg.arr_len, cut_n);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
 #ifdef WA_ANT_TIME
             if (dbg_t_hand) { dbg_t_hand = 0; }
@@ -965,7 +984,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         WA_PHASE(8);
         wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr,
-                                 nullptr, 0, 0, SPARSE ? nullptr : D.arr_len, cut_n);
+                                 nullptr, 0, 0, SPARSE ? nullptr : sg.arr_len, cut_n);
         if (!st.done && st.reason == 5) {
             if (hand_over()) return;
             st.L = D.ltab[st.len - 1];              // the pool is full: the generic loop finishes this ant
@@ -997,7 +1016,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     if (lane == 0) {
         D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
         D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
-        if (st.L != INFINITY && cut_n != 0x7fffffff) __hip_atomic_store(&D.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
+        if (st.L != INFINITY && cut_n != 0x7fffffff) __hip_atomic_store(&sg.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
     }
 }
 
@@ -1122,8 +1141,9 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
     // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on
     if (D.dcount && blockIdx.x == 0 && threadIdx.x == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
     if (D.pool_n && blockIdx.x == 0) {   // stragglers: the next generation starts with no arrivals and an empty pool of its own
-        D.arr_len[threadIdx.x] = 0xffffffffu;
-        if (threadIdx.x == 0) { *D.arr_n = 0; D.pool_n[D.ctl[slot].gen & 1] = 0; }   // (ctl.gen is already the next generation's number)
+        const WaStrag sg = wa_strag_of(D, slot);
+        sg.arr_len[threadIdx.x] = 0xffffffffu;
+        if (threadIdx.x == 0) { *sg.arr_n = 0; sg.pool_n[D.ctl[slot].gen & 1] = 0; }   // (ctl.gen is already the next generation's number)
     }
     if ((int32_t)blockIdx.x < table_blocks) {
         // independent loads first: deposit coefficients, control block, this row's path words
@@ -1161,14 +1181,15 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         // ---- resume block: a straggler of generation gen - 1 (walk_flags bit 5 allowed it to leave that launch) finishes its walk here,
         // on that generation's field, beside this generation's ants; only that generation's statistics hear of it
         const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
-        if (gen < 1 || r >= D.pool_n[pg] || r >= WA_RESUME_MAX) return;
-        const int32_t a = D.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC], n0 = D.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC + 1];
+        const WaStrag sg = wa_strag_of(D, slot);
+        if (gen < 1 || r >= sg.pool_n[pg] || r >= WA_RESUME_MAX) return;
+        const int32_t a = sg.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC], n0 = sg.pool_rec[(pg * WA_RESUME_MAX + r) * WA_POOL_REC + 1];
         WaAcsDev Dp = D;
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         int32_t f0 = 0, b0 = 0, rs0 = 0;
         wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
-                                                 walk_flags & 1, 0u, c->heur_slot, 0x7fffffff, D.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
+                                                 walk_flags & 1, 0u, c->heur_slot, 0x7fffffff, sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
 #ifdef WA_STRAG_TIME
         if (threadIdx.x == 0 && gen < 128) atomicMax(&wa_strag_t[gen * 8 + 3], (unsigned long long)wall_clock64());
@@ -1492,9 +1513,19 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 // :268-272 -- dst = src * rho over n_floats values; float4 per lane, 4 independent float4 in flight per
 // thread, grid-stride over E blocks.  One definition for k_evaporate and the fused k_evap_rank_mark.
 typedef float wa_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p) { return *p; }
-__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v) { *p = v; }
-__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
+// NT bit 0 / bit 1: non-temporal loads / stores (the `nt` bit of global_load / global_store: the lines stream through the caches instead of
+// displacing what is there).  Wrong for a lone search at 128^3 -- the next walk finds the swept field in the Infinity Cache -- and
+// right when several searches share the GPU (their fields are past every cache anyway and the walking groups' records stay in L2)
+template <int NT>
+__device__ __forceinline__ wa_v4f wa_sweep_ld(const wa_v4f *p) { return (NT & 1) ? __builtin_nontemporal_load(p) : *p; }
+template <int NT>
+__device__ __forceinline__ void wa_sweep_st(wa_v4f *p, wa_v4f v)
+{
+    if (NT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <int NT>
+__device__ __forceinline__ void wa_sweep_body_nt(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E)
 {
     const wa_v4f *s4 = reinterpret_cast<const wa_v4f *>(src);
     wa_v4f *d4 = reinterpret_cast<wa_v4f *>(dst);
@@ -1502,18 +1533,27 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
     const int64_t gsz = (int64_t)E * blockDim.x;
     int64_t i = (int64_t)ebx * blockDim.x + threadIdx.x;
     for (; i + 3 * gsz < n4; i += 4 * gsz) {
-        wa_v4f a = wa_sweep_ld(s4 + i), b = wa_sweep_ld(s4 + i + gsz), c = wa_sweep_ld(s4 + i + 2 * gsz), d = wa_sweep_ld(s4 + i + 3 * gsz);
+        wa_v4f a = wa_sweep_ld<NT>(s4 + i), b = wa_sweep_ld<NT>(s4 + i + gsz), c = wa_sweep_ld<NT>(s4 + i + 2 * gsz), d = wa_sweep_ld<NT>(s4 + i + 3 * gsz);
         a *= rho; b *= rho; c *= rho; d *= rho;
-        wa_sweep_st(d4 + i, a); wa_sweep_st(d4 + i + gsz, b); wa_sweep_st(d4 + i + 2 * gsz, c); wa_sweep_st(d4 + i + 3 * gsz, d);
+        wa_sweep_st<NT>(d4 + i, a); wa_sweep_st<NT>(d4 + i + gsz, b); wa_sweep_st<NT>(d4 + i + 2 * gsz, c); wa_sweep_st<NT>(d4 + i + 3 * gsz, d);
     }
     for (; i < n4; i += gsz) {
-        wa_v4f a = wa_sweep_ld(s4 + i);
+        wa_v4f a = wa_sweep_ld<NT>(s4 + i);
         a *= rho;
-        wa_sweep_st(d4 + i, a);
+        wa_sweep_st<NT>(d4 + i, a);
     }
     // tail (n_floats is even; at most 2 floats)
     const int64_t t = (n4 << 2) + (int64_t)ebx * blockDim.x + threadIdx.x;
     if (t < n_floats) dst[t] = src[t] * rho;
+}
+__device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int64_t n_floats, float rho, int32_t ebx, int32_t E, int32_t nt = 0)
+{
+    switch (nt & 3) {   // (uniform over the launch)
+    case 0: wa_sweep_body_nt<0>(src, dst, n_floats, rho, ebx, E); break;
+    case 1: wa_sweep_body_nt<1>(src, dst, n_floats, rho, ebx, E); break;
+    case 2: wa_sweep_body_nt<2>(src, dst, n_floats, rho, ebx, E); break;
+    default: wa_sweep_body_nt<3>(src, dst, n_floats, rho, ebx, E); break;
+    }
 }
 
 // ------------------------------------------------------------------ fused post-walk launch (DEV mode)
@@ -1529,7 +1569,8 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // C5 with 224 searches per launch: 4 blocks 0.636 s, 2 0.622 s, 1 0.623 s) -- the host passes 2 or 1
 template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
-                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period)
+                                                        float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period,
+                                                        int32_t sweep_nt)
 {
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
@@ -1537,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
         if (!SPARSE) {
             wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
-                          (int32_t)blockIdx.x - MB, E);
+                          (int32_t)blockIdx.x - MB, E, sweep_nt);
         } else {
             // lazy evaporation, background pass: every lazy_period-th entry of the dirty list (phase = generation) is brought
             // current in place, so no record has more than ~lazy_period multiplications pending (whoever reads a record applies
@@ -1706,14 +1747,14 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
 // ------------------------------------------------------------------ evaporation (the HBM sweep)
 // :268-272 -- every edge of every voxel, occupied voxels and out-of-bounds edges included:
 // dst = src * rho over 6N floats, 48 B of traffic per voxel (24 read + 24 written).  The
-// pheromone field is double-buffered so that this sweep (which only needs the field the walk
-// is READING) runs on a second stream concurrently with the latency-bound walk; src == dst is
-// allowed (in-place).  float4 per lane, 4 independent float4 in flight per thread, grid-stride.
+// pheromone field is double-buffered: the sweep is out of place (the buffer it reads stays intact until the next
+// sweep -- what a resumed straggler walks on); src == dst is allowed (in-place).  float4 per lane, 4 independent
+// float4 in flight per thread, grid-stride.  sweep_nt: see wa_sweep_body.
 __global__ __launch_bounds__(256) void k_evaporate(const float *src_base, float *dst_base,
-                                                   int64_t stride, int64_t n_floats, float rho)
+                                                   int64_t stride, int64_t n_floats, float rho, int32_t sweep_nt)
 {
     wa_sweep_body(src_base + (int64_t)blockIdx.y * stride, dst_base + (int64_t)blockIdx.y * stride, n_floats, rho,
-                  (int32_t)blockIdx.x, (int32_t)gridDim.x);
+                  (int32_t)blockIdx.x, (int32_t)gridDim.x, sweep_nt);
 }
 
 // ------------------------------------------------------------------ ranked deposit
@@ -2043,8 +2084,9 @@ __global__ __launch_bounds__(256) void k_apply_table26(WaAcsDev D, WaRun R)
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     if (D.pool_n && blockIdx.x == 0) {   // stragglers: the next generation starts with no arrivals and an empty pool of its own (see k_apply_table)
-        D.arr_len[tid] = 0xffffffffu;
-        if (tid == 0) { *D.arr_n = 0; D.pool_n[D.ctl[slot].gen & 1] = 0; }
+        const WaStrag sg = wa_strag_of(D, slot);
+        sg.arr_len[tid] = 0xffffffffu;
+        if (tid == 0) { *sg.arr_n = 0; sg.pool_n[D.ctl[slot].gen & 1] = 0; }
     }
     if (blockIdx.x == 0) { wa_table26_lengths(D, R, slot, s_d); return; }
     if ((int32_t)blockIdx.x <= WA_TABLE26_BLOCKS) {
@@ -2108,6 +2150,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     // its final L, every step adds a positive length -- against them.  res_words != nullptr: a resume block, which finishes the
     // straggler whose path so far (res_len nodes, length res_L) stands in res_words and goes on writing there.
     const int lane = threadIdx.x;
+    const WaStrag sg = wa_strag_of(D, slot);   // (only dereferenced where D.pool_n is set)
     const float *pher = D.pher + (int64_t)slot * D.pher_stride;
     const float *heur = D.heur + (int64_t)D.ctl[slot].heur_slot * D.pher_stride;
     int32_t *path = res_words ? res_words : D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
@@ -2115,7 +2158,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     const bool cutting = MODE == 1 && cut_n != 0x7fffffff;
     auto publish = [&](float Larr) {   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
         if (cutting && lane == 0 && Larr != INFINITY)
-            __hip_atomic_store(&D.arr_len[atomicAdd(D.arr_n, 1u) & 255u], __float_as_uint(Larr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sg.arr_len[atomicAdd(sg.arr_n, 1u) & 255u], __float_as_uint(Larr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto finish = [&](float Lf, int32_t lenf) {   // agents[] of an ant -- or, for a resumed straggler, the rest of its generation's statistics
         if (res_words) {
@@ -2154,7 +2197,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     T.mask = (1u << hash_log2) - 1u;
     T.shift = 32 - hash_log2;
     // (a resume block spills into a bitmap row of its own, behind the ants' rows)
-    T.bits = D.vbits + ((int64_t)slot * D.max_colony + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
+    T.bits = D.vbits + ((int64_t)slot * D.vbits_rows + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
     T.spilled = false;
     const int32_t spill_at = (int32_t)((3u << hash_log2) >> 2);
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
@@ -2278,10 +2321,10 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             if (next == end) { alive = false; break; }
             if (cutting && (len & em) == 0) {   // arrivals of this generation with a smaller L than this ant has already
                 const uint32_t mine = __float_as_uint(L);
-                uint32_t e0 = __hip_atomic_load(&D.arr_len[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t e1 = __hip_atomic_load(&D.arr_len[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t e2 = __hip_atomic_load(&D.arr_len[lane + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t e3 = __hip_atomic_load(&D.arr_len[lane + 192], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e0 = __hip_atomic_load(&sg.arr_len[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e1 = __hip_atomic_load(&sg.arr_len[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e2 = __hip_atomic_load(&sg.arr_len[lane + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t e3 = __hip_atomic_load(&sg.arr_len[lane + 192], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int32_t shorter = __popcll(__ballot(e0 < mine)) + __popcll(__ballot(e1 < mine)) + __popcll(__ballot(e2 < mine)) + __popcll(__ballot(e3 < mine));
                 if (shorter > 0) em = 15;
                 if (shorter >= cut_n) { cut = true; break; }
@@ -2297,10 +2340,10 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             // a straggler: its path so far goes to a pool entry of its generation; agents[] says "not arrived, len nodes" (what the ranking
             // sees); a resume block of the next walk launch finishes it.  Pool full: the ant walks on in the loop below, without the check
             int32_t r = 0;
-            if (lane == 0) r = atomicAdd(&D.pool_n[gen & 1], 1);
+            if (lane == 0) r = atomicAdd(&sg.pool_n[gen & 1], 1);
             r = __builtin_amdgcn_readfirstlane(r);
             if (r < WA_RESUME_MAX) {
-                int32_t *pp = D.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
+                int32_t *pp = sg.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
                 for (int32_t q0 = 0; q0 < len; q0 += 512) {   // (through L2: the last block was stored by this very wavefront a moment ago)
                     int32_t w[8];
 #pragma unroll
@@ -2315,7 +2358,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
                     }
                 }
                 if (lane == 0) {
-                    int32_t *rec = D.pool_rec + ((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC;
+                    int32_t *rec = sg.pool_rec + ((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC;
                     rec[0] = ant; rec[1] = len; rec[2] = __float_as_int(L);
                     D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
                     D.antLen[(int64_t)slot * D.max_colony + ant] = len;
@@ -2323,7 +2366,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
                 }
                 return;
             }
-            if (lane == 0) atomicSub(&D.pool_n[gen & 1], 1);
+            if (lane == 0) atomicSub(&sg.pool_n[gen & 1], 1);
         }
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();   // the hash is nearly full (the loop below moves the set to the bitmap: it reads path[] back) or path[]
@@ -2420,15 +2463,16 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
     if (D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
         // ---- resume block: a straggler of generation gen - 1 finishes its walk here, on that generation's field
         const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
-        if (gen < 1 || r >= D.pool_n[pg] || r >= WA_RESUME_MAX) return;
-        const int32_t *rec = D.pool_rec + (pg * WA_RESUME_MAX + r) * WA_POOL_REC;
+        const WaStrag sg = wa_strag_of(D, slot);
+        if (gen < 1 || r >= sg.pool_n[pg] || r >= WA_RESUME_MAX) return;
+        const int32_t *rec = sg.pool_rec + (pg * WA_RESUME_MAX + r) * WA_POOL_REC;
         const int32_t a = rec[0], n0 = rec[1];
         const float L0 = __int_as_float(rec[2]);
         WaAcsDev Dp = D;
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         wa_walk_one26<1>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, 0, 0x7fffffff,
-                         D.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r);
+                         sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r);
         return;
     }
     if (ant >= colony || colony > D.max_colony) return;

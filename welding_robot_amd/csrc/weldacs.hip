@@ -85,6 +85,15 @@ struct wa_acs {
     std::vector<EvPair> ev;
     double prof_ms[WA_K_COUNT];
     int64_t prof_n[WA_K_COUNT];
+    // pipelined groups (wa_acs_run): the active slots split into groups, each with a stream of its own, so that one group's HBM-bound
+    // sweep runs under another group's latency-bound walk.  Forked from / joined into the context's stream inside every wa_acs_run call.
+    int32_t pipe_groups_env = 0;         // WA_PIPE_GROUPS, read at creation (0: by rule)
+    std::vector<hipStream_t> gstream;
+    std::vector<hipEvent_t> gjoin, gchain;
+    bool pipe_chain = false;             // WA_PIPE_CHAIN: the groups' sweeps run one after another (event chain across the streams)
+    int32_t sweep_nt_env = -1;           // WA_SWEEP_NT: cache policy of the sweep (-1: by rule)
+    hipEvent_t gfork = nullptr;
+    int32_t last_groups = 1;             // groups the last wa_acs_run call used (wa_acs_pipeline_info)
 };
 
 static int fail(wa_ctx *c, int code, const char *fmt, const char *a = "")

@@ -488,6 +488,13 @@ private:
         // only queues: bound the slots by that too
         cap = std::min<int64_t>(cap, std::max<int64_t>(1, (int64_t)3 * 2048 / colony));
         if (cap < 1) cap = 1;
+        // small dense solvers also hold straggler pools per slot (wa_acs_straggler_pool_bytes; none for lazy or > 16 slots)
+        while (cap > 1) {
+            int64_t pools = 0;
+            if (wa_acs_straggler_pool_bytes(device_grid(), (int32_t)std::min<int64_t>(cap, n_pairs), colony, 0, neighbourhood, lazy_ok(colony) ? 1 : 0, &pools) != WA_OK ||
+                pools <= budget - cap * per_slot) break;
+            cap--;
+        }
         const int64_t batches = (n_pairs + cap - 1) / cap;
         return (int)((n_pairs + batches - 1) / batches);
     }
