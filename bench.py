@@ -169,6 +169,7 @@ def walk_step_extra(solver, p, ids, wl, generations=12):
     the issue cost of one instruction of a lone wavefront (microbenchmark): the bound this issue-bound kernel can be held
     against (it is neither an HBM nor an MFMA kernel)."""
     import numpy as np
+    solver.set_stragglers(0)          # every ant finishes inside its own launch here: launch time = the longest walk
     solver.init_pheromone(1.0)
     solver.begin(p, ids[0], ids[1], streams=[wl["stream"]])
     ns = []
@@ -179,6 +180,7 @@ def walk_step_extra(solver, p, ids, wl, generations=12):
         _, lens = solver.ants()
         ns.append(pr["walk"]["ms"] * 1e6 / max(int(lens.max()) - 1, 1))
     solver.profile(False, 1)
+    solver.set_stragglers(-1)
     step = float(np.median(ns))
     out = {"ns_per_step_of_the_longest_walk": step, "generations_sampled": generations,
            "source": "walk launch time / max(ant steps) per generation"}

@@ -215,14 +215,23 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
 /* diagnostic counters.  Product build: out16[9] = ants handed over as stragglers, out16[7] = stragglers finished by a resume block (the two
  * are equal after wa_acs_run returns), everything else zero; the cycle counters of the walk's inner loop only exist in the diagnostic
  * builds (-DWA_STAMPS / -DWA_ANT_TIME, tools/).
- * Stragglers (a single dense search of at most 256 ants, 6 or 26 neighbours, DEV mode, alpha == 1, the first 64 generations of a search): only the
- * ranks o <= lambda - 1 deposit (ACSRank_3D.hpp:200) and only the shortest ant can become the best path (:263-264), so an ant that is
- * already longer than floor(lambda - 1) + 1 arrivals of its generation (26 neighbours: whose L so far already exceeds theirs) can change neither (about 140 of 256 ants per exploratory generation); at one of the loop's checks (every 64 nodes, every 16 once shorter ants have arrived) it leaves the walk
- * launch -- which lasts as long as its longest ant -- and a resume block of the NEXT generation's walk launch finishes the same walk on the
- * previous generation's field (intact until the next sweep), adding its arrival and its steps to its own generation's trace entry.  The
- * last generation of a wa_acs_run call hands nothing over, so agents[] and the trace are complete when the call's work is.  Results are
- * bit-identical with the mechanism on or off (WA_STRAGGLERS=0, read at wa_acs_create). */
+ * Stragglers (dense searches of at most 256 ants in solvers of at most 16 slots, 6 or 26 neighbours, DEV mode, alpha == 1, the first 64
+ * generations of a search): only the ranks o <= lambda - 1 deposit (ACSRank_3D.hpp:200) and only the shortest ant can become the best path
+ * (:263-264), so an ant that is already longer than floor(lambda - 1) + 1 arrivals of its generation (26 neighbours: whose L so far
+ * already exceeds theirs) can change neither (about 140 of 256 ants per exploratory generation); at one of the loop's checks (every 64
+ * nodes, every 16 once shorter ants have arrived) it leaves the walk launch -- which lasts as long as its longest ant -- and a resume
+ * block of the NEXT generation's walk launch finishes the same walk on the previous generation's field (intact until the next sweep),
+ * adding its arrival and its steps to its own generation's trace entry.  Lists and pools are per slot: every search of a batch hands
+ * its own stragglers over.  The last generation of a wa_acs_run call hands over too; its stragglers are finished by the next call's
+ * first walk launch or -- when results are read first (wa_acs_sync, wa_acs_result, wa_acs_trace, wa_acs_read_ants ...) -- by a launch of
+ * resume blocks only, which also puts the finished walks back into agents[] (WA_STRAGGLER_DRAIN=0: the last generation of a call
+ * hands nothing over, as in round 3).  agents[] and the trace are complete whenever they are read.  Results are bit-identical with
+ * the mechanism on or off (WA_STRAGGLERS=0, read at wa_acs_create; wa_acs_set_stragglers(s, 0) at run time). */
 int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
+/* the same two counts per slot (ants handed over / stragglers finished by a resume block; equal whenever they are read) */
+int wa_acs_straggler_counters(wa_acs *s, int32_t slot, uint64_t *handed_over, uint64_t *resumed, int32_t reset);
+/* generations of a search during which its ants may be handed over (default 64, WA_STRAGGLER_GENS; 0: off; < 0: back to the default) */
+int wa_acs_set_stragglers(wa_acs *s, int32_t generations);
 /* evaporation sweep alone (ACSRank_3D.hpp:268-272) over `slot` -- for roofline measurements */
 int wa_acs_evaporate(wa_acs *s, int32_t slot, float rho, int32_t repeats);
 

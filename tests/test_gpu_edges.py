@@ -319,49 +319,73 @@ def test_profile_can_stamp_the_sweep_launch_of_every_generation(ctx):
     s.close()
 
 
+_strag_oracle = {}
+
+
+def _strag_want(og, n, nb, stream, iters=14, seed=77):
+    key = (nb, stream, iters, seed)
+    if key not in _strag_oracle:
+        a = O.Acs(og, nb=nb)
+        tr = a.solve(0, n - 1, iters, 132.0, fixed_colony=96, mode=O.DEV, seed=seed, stream=stream)
+        olens, oL = a.last_ants()
+        paths = a.last_paths()
+        _strag_oracle[key] = (tr["steps"].copy(), tr["finite"].copy(), bits(tr["bestL"]).copy(), bits(oL).copy(), olens.copy(), bits(a.pheromone()).copy(), paths)
+    return _strag_oracle[key]
+
+
+@pytest.mark.parametrize("P", [1, 2, 8])
 @pytest.mark.parametrize("nb", [6, 26])
-def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch, nb):
-    """A single dense search hands ants that can no longer matter to resume blocks of the next walk launch (include/weldacs.h,
-    wa_acs_debug_counters).  With the mechanism on, off, and run generation by generation (where it never engages): the same trace --
-    steps and finite ants included --, the same ants in the last generation, the same field, all equal to the oracle.  26 neighbours: the arrivals are compared by their L
-    (step lengths differ per move type), a resumed ant continues its in-order fp32 sum."""
+def test_stragglers_are_handed_over_and_nothing_changes(ctx, monkeypatch, nb, P):
+    """Dense searches hand ants that can no longer matter to resume blocks of the next walk launch (include/weldacs.h,
+    wa_acs_debug_counters), every search of a batch its own (lists and pools per slot: P = 1, 2, 8 searches in one solver).  With the
+    mechanism on, off, run generation by generation with a read in between (the last generation of a call hands over too and a drain launch
+    finishes its stragglers) and the same with WA_STRAGGLER_DRAIN=0 (where it then never engages): the same trace -- steps and finite ants
+    included --, the same ants in the last generation, the same field, all equal to the oracle.  26 neighbours: the arrivals are compared
+    by their L (step lengths differ per move type), a resumed ant continues its in-order fp32 sum."""
     og = box_grid(48, 40, 44, occ_prob=0.1, seed=21)
     og.free[0] = og.free[-1] = 1
     n = 48 * 40 * 44
     out = np.zeros(16, np.uint64)
-    res = {}
-    for mode in ("on", "off", "stepwise"):
+    streams = [4 + q for q in range(P)]
+    for mode in ("on", "off", "stepwise", "stepwise_nodrain"):
         monkeypatch.setenv("WA_STRAGGLERS", "0" if mode == "off" else "1")
+        monkeypatch.setenv("WA_STRAGGLER_DRAIN", "0" if mode == "stepwise_nodrain" else "1")
         dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
-        s = api.AcsSolver(ctx, dg, 1, 96, neighbourhood=nb)
+        s = api.AcsSolver(ctx, dg, P, 96, neighbourhood=nb)
         p = api.default_params(max_iteration=14, predict=132.0, fixed_colony=96, rng_mode=api.RNG_DEV, seed=77)
         s.init_pheromone(1.0)
         ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 1))
-        if mode == "stepwise":
-            s.begin(p, 0, n - 1, streams=[4])
-            for _ in range(14):
+        if mode.startswith("stepwise"):
+            s.begin(p, [0] * P, [n - 1] * P, streams=streams)
+            for g in range(14):
                 s.run(1)
+                if g % 3 == 0:      # a read between the calls: complete whenever it happens
+                    L, lens = s.ants(P - 1)
+                    assert np.all(lens >= 1) and (np.isinf(L) | (lens > 1)).all()
             s.sync()
         else:
-            s.solve(p, 0, n - 1, streams=[4])
+            s.solve(p, [0] * P, [n - 1] * P, streams=streams)
         ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
         handed, resumed = int(out[9]), int(out[7])
-        if mode == "on":
+        per_slot = [s.straggler_counters(q) for q in range(P)]
+        assert sum(h for h, _ in per_slot) == handed and all(h == r for h, r in per_slot)
+        if mode in ("on", "stepwise"):
             assert handed > 0 and resumed == handed       # it engaged, and every straggler was finished
+            assert all(h > 0 for h, _ in per_slot)        # ... in every search of the batch
         else:
             assert handed == 0 and resumed == 0
-        t = s.trace()
-        L, lens = s.ants()
-        res[mode] = (t["steps"].copy(), t["finite"].copy(), bits(t["bestL"]), bits(L), lens.copy(), bits(s.pheromone()))
+        for q in range(P):
+            t = s.trace(q)
+            L, lens = s.ants(q)
+            got = (t["steps"], t["finite"], bits(t["bestL"]), bits(L), lens, bits(s.pheromone(q)))
+            want = _strag_want(og, n, nb, streams[q])
+            for g_, w in zip(got, want[:6]):
+                assert np.array_equal(g_, w), (mode, q)
+            if q == P - 1:   # every ant's whole path: the ants the LAST generation handed over were finished by the drain launch and put back
+                for i, op in enumerate(want[6]):
+                    assert np.array_equal(s.ant_path(i, q), op), (mode, q, i)
         s.close()
         dg.close()
-    a = O.Acs(og, nb=nb)
-    tr = a.solve(0, n - 1, 14, 132.0, fixed_colony=96, mode=O.DEV, seed=77, stream=4)
-    olens, oL = a.last_ants()
-    want = (tr["steps"], tr["finite"], bits(tr["bestL"]), bits(oL), olens, bits(a.pheromone()))
-    for mode in res:
-        for got, w in zip(res[mode], want):
-            assert np.array_equal(got, w), mode
 
 
 @pytest.mark.parametrize("nb", [6, 26])

@@ -202,6 +202,16 @@ class AcsSolver:
     def sync(self):
         self.ctx.check(self.ctx.lib.wa_acs_sync(self.h))
 
+    def straggler_counters(self, slot=0, reset=False):
+        """(ants handed over, stragglers finished by a resume block) of one slot"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.lib.wa_acs_straggler_counters(self.h, slot, C.byref(a), C.byref(b), 1 if reset else 0))
+        return a.value, b.value
+
+    def set_stragglers(self, generations):
+        """generations of a search during which ants may be handed over (0: off, < 0: default)"""
+        self.ctx.check(self.ctx.lib.wa_acs_set_stragglers(self.h, generations))
+
     def set_pipeline(self, groups):
         """groups of slots that advance on streams of their own inside run() (0: by rule, 1: one stream)"""
         self.ctx.check(self.ctx.lib.wa_acs_set_pipeline(self.h, groups))

@@ -63,6 +63,7 @@ struct WaAcsDev {
     int32_t *pool_n;               // [slot][2]   stragglers of generation g in pool [g & 1]
     int32_t *pool_rec;             // [slot][2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
     int32_t *pool_path;            // [slot][2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
+    unsigned long long *strag_cnt; // [slot][2]  ants handed over / stragglers finished by a resume block, per slot (wa_acs_straggler_counters)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
@@ -892,6 +893,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
 #ifndef WA_ANT_TIME
             if (D.dbg) atomicAdd(&D.dbg[9], 1ULL);   // ants handed over since the counters were last reset (wa_acs_debug_counters)
+            atomicAdd(&D.strag_cnt[slot * 2], 1ULL);
 #endif
         }
         return true;
@@ -1005,11 +1007,21 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     if (res_words) {   // a resumed straggler: the rest of its walk belongs to generation `gen`'s statistics
 #ifndef WA_ANT_TIME
         if (lane == 0 && D.dbg) atomicAdd(&D.dbg[7], 1ULL);   // ... and stragglers finished by a resume block
+        if (lane == 0) atomicAdd(&D.strag_cnt[slot * 2 + 1], 1ULL);
 #endif
         if (lane == 0 && gen < D.trace_cap) {
             const int64_t t = (int64_t)slot * D.trace_cap + gen;
             if (st.L != INFINITY) atomicAdd(&D.trFinite[t], 1);
             atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(st.len - res_len));
+        }
+        if (walk_flags & 64) {   // drain launch (no newer generation's ant owns the slot): the finished walk goes back to agents[]
+            int32_t *own = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+            __threadfence();     // (the last words were stored by this wavefront; read them back through L2)
+            for (int32_t q = lane; q < st.len; q += 64) own[q] = __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+            }
         }
         return;
     }
@@ -1189,13 +1201,14 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         int32_t f0 = 0, b0 = 0, rs0 = 0;
         wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
-                                                 walk_flags & 1, 0u, c->heur_slot, 0x7fffffff, sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
+                                                 walk_flags & (1 | 64), 0u, c->heur_slot, 0x7fffffff, sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
 #ifdef WA_STRAG_TIME
         if (threadIdx.x == 0 && gen < 128) atomicMax(&wa_strag_t[gen * 8 + 3], (unsigned long long)wall_clock64());
 #endif
         return;
     }
+    if (walk_flags & 64) return;   // a drain launch (wa_acs_sync and friends behind a call whose last generation handed over) only resumes
     if (ant >= colony || colony > D.max_colony) return;  // overflow is flagged by the rank step
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     int32_t f = 0, b = 0, rs_unused = 0;
@@ -2143,7 +2156,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
                                               int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t &rng_rs,
                                               int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen,
                                               int32_t cut_n = 0x7fffffff, int32_t *res_words = nullptr, int32_t res_len = 0, float res_L = 0.f,
-                                              int32_t gen = 0, int32_t bits_row = -1)
+                                              int32_t gen = 0, int32_t bits_row = -1, bool drain = false)
 {
     // Stragglers (see wa_walk_one / k_walk_dev): step lengths differ per move type here, so the arrivals publish the bits of
     // their L (positive floats order like unsigned integers) and an ant compares the L it has accumulated so far -- a lower bound of
@@ -2164,10 +2177,20 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         if (res_words) {
             if (lane == 0) {
                 if (D.dbg) atomicAdd(&D.dbg[7], 1ULL);
+                atomicAdd(&D.strag_cnt[slot * 2 + 1], 1ULL);
                 if (gen < D.trace_cap) {
                     const int64_t t = (int64_t)slot * D.trace_cap + gen;
                     if (Lf != INFINITY) atomicAdd(&D.trFinite[t], 1);
                     atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(lenf - res_len));
+                }
+            }
+            if (drain) {   // drain launch (see k_walk_dev): the finished walk goes back to agents[]
+                int32_t *own = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
+                __threadfence();
+                for (int32_t q = lane; q < lenf; q += 64) own[q] = __hip_atomic_load(&res_words[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    D.antL[(int64_t)slot * D.max_colony + ant] = Lf;
+                    D.antLen[(int64_t)slot * D.max_colony + ant] = lenf;
                 }
             }
             return;
@@ -2363,6 +2386,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
                     D.antL[(int64_t)slot * D.max_colony + ant] = INFINITY;
                     D.antLen[(int64_t)slot * D.max_colony + ant] = len;
                     if (D.dbg) atomicAdd(&D.dbg[9], 1ULL);
+                    atomicAdd(&D.strag_cnt[slot * 2], 1ULL);
                 }
                 return;
             }
@@ -2472,9 +2496,10 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         wa_walk_one26<1>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, 0, 0x7fffffff,
-                         sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r);
+                         sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r, (walk_flags & 64) != 0);
         return;
     }
+    if (walk_flags & 64) return;   // drain launch: resume blocks only
     if (ant >= colony || colony > D.max_colony) return;
     const uint64_t antkey = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)gen), (uint32_t)ant);
     const int32_t rlen = (D.rtab && c->bestL != INFINITY) ? c->best_len : 0;
