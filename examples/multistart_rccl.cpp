@@ -5,7 +5,8 @@
 // This is the shape a multi-start main.cpp:268-283 takes on an 8 x MI355X node.
 //
 //   multistart_rccl <grid n> <ants> <generations> <devices: "all" | "0" | "0,1,..."> <dump.txt>
-// dump: "local r g BESTBITS" per rank and generation, "global g BESTBITS" per generation, "gens_per_s X".
+// dump: "local r g BESTBITS" per rank and generation, "global g BESTBITS OWNER_RANK OWNER_SLOT" per generation, "gens_per_s X",
+// then the path that achieved the final global best, fetched from its owner: "owner_path RANK N" + N node ids (wa_comm_gather_paths).
 // g++ -std=c++14 -I include examples/multistart_rccl.cpp -L welding_robot_amd/lib -lweldacs -lpthread
 #include <chrono>
 #include <cstdio>
@@ -42,6 +43,9 @@ struct Rank {
     int rc = WA_OK;
     std::string err;
     std::vector<float> local, global;
+    std::vector<int32_t> owner_rank, owner_slot;
+    std::vector<int32_t> gathered_index, gathered_ids;   // rank 0: every rank's best path (index = rank)
+    std::vector<int64_t> gathered_len;
     double seconds = 0;
 };
 
@@ -91,12 +95,28 @@ int main(int argc, char **argv)
         if (!rc) rc = wa_acs_sync(s);
         me.global.resize((size_t)K);
         me.local.resize((size_t)K);
-        if (!rc) rc = wa_comm_read_best(c, 0, K, me.global.data());
+        me.owner_rank.resize((size_t)K);
+        me.owner_slot.resize((size_t)K);
+        if (!rc) rc = wa_comm_read_best_owner(c, 0, K, me.global.data(), me.owner_rank.data(), me.owner_slot.data());
         if (!rc) rc = wa_comm_barrier(c);
         me.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         int32_t gd = 0;
         if (!rc) rc = wa_acs_trace(s, 0, &gd, me.local.data(), NULL, NULL, NULL, NULL);
         if (!rc) rc = wa_comm_allreduce_f64(c, &me.seconds, 1, WA_COMM_MAX);   // the slowest rank's time
+        // the path behind the global best lives on its owner: every rank hands its best path (index = its rank) to rank 0
+        float cost = 0;
+        int64_t len = 0;
+        std::vector<int32_t> path;
+        if (!rc) rc = wa_acs_result(s, 0, &cost, &len, NULL, NULL, 0);
+        path.resize((size_t)len);
+        if (!rc && len > 0) rc = wa_acs_result(s, 0, &cost, &len, path.data(), NULL, len);
+        int64_t np = 0, ni = 0;
+        const int32_t my_index = r;
+        if (!rc) rc = wa_comm_gather_paths(c, 0, len > 0 ? 1 : 0, &my_index, &len, path.data(), &np, &ni);
+        if (!rc && r == 0) {
+            me.gathered_index.resize((size_t)np); me.gathered_len.resize((size_t)np); me.gathered_ids.resize((size_t)ni);
+            rc = wa_comm_gathered_paths_read(c, me.gathered_index.data(), me.gathered_len.data(), me.gathered_ids.data());
+        }
         if (rc) bail(rc);
         if (s) wa_acs_destroy(s);
         if (g) wa_grid_destroy(g);
@@ -114,8 +134,20 @@ int main(int argc, char **argv)
     auto bitsof = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
     for (int r = 0; r < W; r++)
         for (int g = 0; g < K; g++) fprintf(fp, "local %d %d %08x\n", r, g, bitsof(R[r].local[g]));
-    for (int g = 0; g < K; g++) fprintf(fp, "global %d %08x\n", g, bitsof(R[0].global[g]));
+    for (int g = 0; g < K; g++) fprintf(fp, "global %d %08x %d %d\n", g, bitsof(R[0].global[g]), R[0].owner_rank[g], R[0].owner_slot[g]);
     fprintf(fp, "gens_per_s %.3f\n", (double)K * W / R[0].seconds);
+    {   // the final global best's path, as rank 0 received it from its owner
+        const int owner = R[0].owner_rank[K - 1];
+        size_t off = 0;
+        for (size_t i = 0; i < R[0].gathered_index.size(); i++) {
+            if (R[0].gathered_index[i] == owner) {
+                fprintf(fp, "owner_path %d %lld", owner, (long long)R[0].gathered_len[i]);
+                for (int64_t q = 0; q < R[0].gathered_len[i]; q++) fprintf(fp, " %d", R[0].gathered_ids[off + (size_t)q]);
+                fprintf(fp, "\n");
+            }
+            off += (size_t)R[0].gathered_len[i];
+        }
+    }
     fclose(fp);
     printf("[multistart] %d rank(s), %d generations each, %.1f generations/s whole job, global best %.3f\n", W, K, (double)K * W / R[0].seconds, R[0].global[K - 1]);
     return 0;

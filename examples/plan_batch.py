@@ -2,15 +2,17 @@
 """BASELINE config C5 in miniature or at full size: P weld points on an n^3 grid, all P(P-1)/2
 pair searches (ACS_Rank::searchBestPathOfPoints' loop, ACSRank_3D.hpp:472-499) batched across the
 slots of each GPU and dealt longest-first across ranks, then the weld-seam order by the ACS-TSP
-kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip), then
-(single-rank runs) the tour's segments stitched and smoothed on the device (main.cpp:283-352).
+kernel (ACS_GTSP.hpp:255-284) from the in-memory cost matrix (no graph.in round trip), then on rank 0
+the tour's segments stitched and smoothed on the device (main.cpp:283-352).
 
     python examples/plan_batch.py --grid 256 --points 64 --generations 150          # 1 GPU
-    torchrun --nproc-per-node 8 examples/plan_batch.py --grid 256 --points 64       # 8 GPUs
+    torchrun --nproc-per-node 8 examples/plan_batch.py --grid 256 --points 64       # 8 GPUs (torchrun only starts the processes)
 
 Every pair uses its GLOBAL pair index as DEV-mode stream key, so the cost matrix -- and the tour --
-do not depend on the number of ranks or slots.  The only collective is one SUM all-reduce of the
-P x P cost matrix (each rank fills its own pairs) at the end: 16 KB at P = 64.
+do not depend on the number of ranks or slots.  One process per GPU; the exchanges at the end are the library's own
+(RCCL behind the C ABI, no torch): wa_comm_allgather_costs brings every pair's cost to every rank (8 KB at P = 64) and
+wa_comm_gather_paths every pair's path to rank 0, which orders the seams and stitches (ACS_GTSP.hpp:286-298 needs all of
+best_matrix on one rank).  WA_FORCE_DIST=1 runs the same exchanges with the one rank a 1-GPU box has.
 """
 import argparse
 import json
@@ -84,13 +86,12 @@ def main():
                     help="wa_acs_create_lazy: never-deposited voxels are not swept (same results, O(deposited voxels) per generation)")
     args = ap.parse_args()
     rank, local_rank, world = wd.env_rank()
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = api.Context(local_rank)
+    comm = None
+    if world > 1 or os.environ.get("WA_FORCE_DIST") == "1":
+        uid = wd.ship_unique_id(rank, world, api.Comm.unique_id)      # 128 bytes from rank 0 over a socket: no torch, no MPI
+        comm = api.Comm(ctx, rank, world, np.frombuffer(uid, np.uint8))
+        comm.barrier()
     wait_for_device_memory(ctx)
     n = args.grid
     free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
@@ -99,10 +100,18 @@ def main():
     predict = float(0.35 ** -1 * 24)  # 24 ants per search at precision 1 (ACSRank_3D.hpp:247)
     t0 = time.perf_counter()
     cost, paths, n_mine = plan(ctx, grid, pts, args.generations, predict, args.seed, args.slots, rank, world, lazy=args.lazy)
-    if world > 1:
-        t = torch.from_numpy(cost).cuda()
-        dist.all_reduce(t)  # every pair is owned by exactly one rank
-        cost = t.cpu().numpy()
+    if comm is not None:
+        # every pair is owned by exactly one rank: its cost goes to every rank, its path to rank 0 (the library's own collectives)
+        P = args.points
+        pair_list = [(i, j) for i in range(P) for j in range(i + 1, P)]
+        index_of = {ij: k for k, ij in enumerate(pair_list)}
+        mine = sorted(index_of[ij] for ij in paths)
+        vec = comm.allgather_costs(mine, [cost[pair_list[k]] for k in mine], len(pair_list))
+        cost = np.zeros((P, P), np.float64)
+        for k, (i, j) in enumerate(pair_list):
+            cost[i, j] = cost[j, i] = vec[k]
+        gathered = comm.gather_paths({k: paths[pair_list[k]] for k in mine}, root=0)
+        paths = {pair_list[k]: ids for k, ids in gathered.items()}    # rank 0: all of them; elsewhere empty
     t_pairs = time.perf_counter() - t0
     finite = np.isfinite(cost).all()
     t_pairs -= plan.last_create_s
@@ -114,29 +123,29 @@ def main():
         out.update(tour_cost=float(tour["L"][0]), tour_iterations=int(tour["iters"][0]),
                    order=[int(e[0]) for e in tour["edges"][0]], t_gtsp_s=time.perf_counter() - t1,
                    pair_generations_per_s=out["pairs"] * args.generations / t_pairs)
-        if world == 1:  # main.cpp:283-352: stitch the tour's segments, then the two smoothing passes, all on the device
-            t2 = time.perf_counter()
-            edges = tour["edges"][0][:-1]
-            segs = [paths[(min(a, b), max(a, b))] for a, b in edges]
-            rev = [1 if a > b else 0 for a, b in edges]          # stored i<j; walk them in tour direction
-            path = api.Trajectory.stitch(grid, segs, rev)
-            ends = path.points()[[0, -1]]
-            s1 = api.Bspline(ctx, 3, 0, 0, 0, len(path))          # BS_Basic<float,3,0,0,0>: time-indexed resampling
-            s1.set_param(ends[0], ends[1], path, 150.0)
-            n1 = max(16, len(path) // 8)
-            _, _, coarse = s1.sample(150.0 / n1, 150.0 / n1, n1, host=False, device=True)
-            s2 = api.Bspline(ctx, 3, 3, 2, 2, len(coarse))        # cubic with zero end velocity / acceleration
-            z = np.zeros((2, 3), np.float32)
-            s2.set_param(np.vstack([ends[:1], z]), np.vstack([ends[1:], z]), coarse, 6000.0)
-            traj, ok = s2.sample(0.0, 1.0, 6001)                  # 1 kHz over 6 s
-            out.update(stitched_nodes=len(path), coarse_points=len(coarse), trajectory_samples=int(ok.sum()),
-                       trajectory_length=float(np.linalg.norm(np.diff(traj, axis=0), axis=1).sum()),
-                       t_trajectory_s=time.perf_counter() - t2)
+        # main.cpp:283-352: stitch the tour's segments (rank 0 holds every path), then the two smoothing passes, all on the device
+        t2 = time.perf_counter()
+        edges = tour["edges"][0][:-1]
+        segs = [paths[(min(a, b), max(a, b))] for a, b in edges]
+        rev = [1 if a > b else 0 for a, b in edges]          # stored i<j; walk them in tour direction
+        path = api.Trajectory.stitch(grid, segs, rev)
+        ends = path.points()[[0, -1]]
+        s1 = api.Bspline(ctx, 3, 0, 0, 0, len(path))          # BS_Basic<float,3,0,0,0>: time-indexed resampling
+        s1.set_param(ends[0], ends[1], path, 150.0)
+        n1 = max(16, len(path) // 8)
+        _, _, coarse = s1.sample(150.0 / n1, 150.0 / n1, n1, host=False, device=True)
+        s2 = api.Bspline(ctx, 3, 3, 2, 2, len(coarse))        # cubic with zero end velocity / acceleration
+        z = np.zeros((2, 3), np.float32)
+        s2.set_param(np.vstack([ends[:1], z]), np.vstack([ends[1:], z]), coarse, 6000.0)
+        traj, ok = s2.sample(0.0, 1.0, 6001)                  # 1 kHz over 6 s
+        out.update(stitched_nodes=len(path), coarse_points=len(coarse), trajectory_samples=int(ok.sum()),
+                   trajectory_length=float(np.linalg.norm(np.diff(traj, axis=0), axis=1).sum()),
+                   t_trajectory_s=time.perf_counter() - t2)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -248,13 +248,32 @@ int wa_comm_unique_id(uint8_t id_out[WA_COMM_ID_BYTES]);
 int wa_comm_create(wa_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[WA_COMM_ID_BYTES], wa_comm **out);
 void wa_comm_destroy(wa_comm *c);
 int wa_comm_info(const wa_comm *c, int32_t *rank, int32_t *world);
-/* global_best[g] = MIN over all ranks and all active slots of best_L[g] for g in [gen0, gen0 + count): asynchronous --
- * waits (event) for the generations enqueued so far, runs on the communicator's stream beside the generations enqueued
- * afterwards.  Every rank must call it with the same (gen0, count) sequence.  The global best is published, never fed
- * back into a problem's own colony / Q, so per-problem results equal the single-GPU run. */
+/* global_best[g] = MIN over all ranks and all active slots of best_L[g] for g in [gen0, gen0 + count), together with WHO holds it:
+ * one ncclAllReduce(ncclUint64, ncclMin) of the packed key (float bits of the cost << 32 | rank << 16 | slot; costs are non-negative
+ * or +inf, so the bits order like the values; ties go to the lowest rank, then the lowest slot).  Asynchronous -- waits (event) for
+ * the generations enqueued so far, runs on the communicator's stream beside the generations enqueued afterwards.  Every rank must
+ * call it with the same (gen0, count) sequence.  The global best is published, never fed back into a problem's own colony / Q, so
+ * per-problem results equal the single-GPU run.  At most 65 536 active slots per rank. */
 int wa_acs_allreduce_best(wa_acs *s, wa_comm *c, int32_t gen0, int32_t count);
-/* wait for the exchanges enqueued so far, then copy global_best[gen0 .. gen0 + count) to the host */
+/* wait for the exchanges enqueued so far, then copy global_best[gen0 .. gen0 + count) to the host; WA_ERR_STATE for a generation that
+ * has not been through wa_acs_allreduce_best.  ..._owner: also the rank and the slot whose search holds that cost (its path:
+ * wa_acs_result on that rank; wa_comm_gather_paths brings it to one rank); any output may be NULL. */
 int wa_comm_read_best(wa_comm *c, int32_t gen0, int32_t count, float *out);
+int wa_comm_read_best_owner(wa_comm *c, int32_t gen0, int32_t count, float *cost, int32_t *owner_rank, int32_t *owner_slot);
+/* the packed key itself, for a host that runs the reduction through another transport (host-side helpers, no device work) */
+int wa_comm_pack_best_key(float cost, int32_t rank, int32_t slot, uint64_t *key);
+int wa_comm_unpack_best_key(uint64_t key, float *cost, int32_t *rank, int32_t *slot);
+/* End of a sharded pair-planning run (every rank ran its share of ACSRank_3D.hpp:472-499; ACS_GTSP.hpp:224-253 wants all costs,
+ * :286-298 all paths on one rank).  Both are blocking and size-prefixed (an all-gather of the counts, then the padded records).
+ * wa_comm_allgather_costs: all[index_mine[i]] = cost_mine[i] for every rank's pairs, on every rank (entries nobody owns keep what
+ * the caller put there).
+ * wa_comm_gather_paths: rank `root` receives every rank's paths (path i: global index index_mine[i], len_mine[i] node ids, all ids
+ * back to back in ids_mine) by ncclSend / ncclRecv; on the root the totals come back and wa_comm_gathered_paths_read copies them out
+ * in rank order (index_out / len_out: n_paths_total entries, ids_out: n_ids_total); on the other ranks the totals are 0. */
+int wa_comm_allgather_costs(wa_comm *c, int32_t n_mine, const int32_t *index_mine, const float *cost_mine, int32_t n_total, float *all);
+int wa_comm_gather_paths(wa_comm *c, int32_t root, int32_t n_mine, const int32_t *index_mine, const int64_t *len_mine, const int32_t *ids_mine,
+                         int64_t *n_paths_total, int64_t *n_ids_total);
+int wa_comm_gathered_paths_read(wa_comm *c, int32_t *index_out, int64_t *len_out, int32_t *ids_out);
 /* bookkeeping helpers for a C++ launcher (timing max over ranks, totals): blocking all-reduce of host doubles */
 enum { WA_COMM_MIN = 0, WA_COMM_MAX = 1, WA_COMM_SUM = 2 };
 int wa_comm_allreduce_f64(wa_comm *c, double *inout, int32_t count, int32_t op);

@@ -76,7 +76,72 @@ def test_allreduce_best_with_one_rank_really_reduces_and_overlaps():
     comm.barrier()
     with pytest.raises(api.WeldacsError):
         comm.read_best(0, 100000)
+    # the owner word: which slot of which rank holds the path behind the global best (ties: the lower slot)
+    cost, rk, sl = comm.read_best_owner(0, K)
+    assert np.array_equal(bits(cost), bits(glob)) and np.all(rk == 0)
+    assert np.array_equal(sl, np.where(bits(t1) < bits(t0), 1, 0))
     comm.close(); s.close(); dg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_only_exchanged_generations_can_be_read():
+    """a generation inside the allocated history that never went through wa_acs_allreduce_best is refused (it used to come back as
+    uninitialised device memory with WA_OK)"""
+    ctx = api.Context(0)
+    og = O.synth_grid(24, seed=5, occ_prob=0.1)
+    free = np.nonzero(og.free)[0]
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=16)
+    comm = api.Comm(ctx, 0, 1, api.Comm.unique_id())
+    p = api.default_params(max_iteration=40, predict=60.0, fixed_colony=16, rng_mode=api.RNG_DEV, seed=2)
+    s.init_pheromone(1.0)
+    s.begin(p, int(free[0]), int(free[-1]))
+    s.run(40)
+    comm.allreduce_best(s, 10, 5)                    # generations 10..14 only
+    assert comm.read_best(10, 5).shape == (5,)
+    for g0, cnt in ((0, 5), (9, 2), (14, 2), (15, 1), (2 ** 31 - 2, 2)):
+        with pytest.raises(api.WeldacsError):
+            comm.read_best(g0, cnt)
+    comm.allreduce_best(s, 0, 10)
+    assert np.array_equal(bits(comm.read_best(0, 15)), bits(s.trace()["bestL"][:15]))
+    comm.close(); s.close(); dg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_costs_and_paths_of_a_sharded_pair_run_reach_the_stitching_rank():
+    """SURVEY 8(e)'s end-of-run exchanges behind the C ABI with the ranks a 1-GPU box has: wa_comm_allgather_costs (size-prefixed
+    ncclAllGather) and wa_comm_gather_paths (size-prefixed gather to the root) are really issued over the world of one rank."""
+    ctx = api.Context(0)
+    comm = api.Comm(ctx, 0, 1, api.Comm.unique_id())
+    rs = np.random.RandomState(4)
+    idx = rs.permutation(40)[:17].astype(np.int32)
+    cost = rs.uniform(1, 500, 17).astype(np.float32)
+    cost[3] = np.inf                                  # "no path" is a valid cost (SURVEY Q9)
+    allc = comm.allgather_costs(idx, cost, 40)
+    want = np.full(40, np.nan, np.float32)
+    want[idx] = cost
+    assert np.array_equal(bits(allc), bits(want))
+    assert comm.allgather_costs([], [], 5).shape == (5,) and np.isnan(comm.allgather_costs([], [], 5)).all()
+    with pytest.raises(api.WeldacsError):
+        comm.allgather_costs([40], [1.0], 40)
+    paths = {int(k): rs.randint(0, 10 ** 6, int(rs.randint(0, 300))).astype(np.int32) for k in idx}
+    got = comm.gather_paths(paths, root=0)
+    assert set(got) == set(paths) and all(np.array_equal(got[k], paths[k]) for k in paths)
+    assert comm.gather_paths({}, root=0) == {}
+    comm.close(); ctx.close()
+
+
+def test_best_key_packs_cost_and_owner_in_one_orderable_word():
+    """host-side helpers of the global-best exchange (no device work): the key orders by cost first, then by rank, then by slot"""
+    k = api.pack_best_key
+    assert k(1.5, 0, 0) < k(2.5, 0, 0) < k(np.inf, 0, 0) and k(0.0, 3, 7) < k(1e-38, 0, 0)
+    assert k(7.0, 1, 5) < k(7.0, 2, 0) and k(7.0, 2, 0) < k(7.0, 2, 1)
+    assert api.unpack_best_key(k(378.0, 6, 123)) == (np.float32(378.0), 6, 123)
+    c, r, s_ = api.unpack_best_key(k(np.inf, 7, 65535))
+    assert np.isinf(c) and (r, s_) == (7, 65535)
+    for bad in ((-1.0, 0, 0), (np.nan, 0, 0), (1.0, -1, 0), (1.0, 0, 65536), (1.0, 32768, 0)):
+        with pytest.raises(api.WeldacsError):
+            k(*bad)
 
 
 @pytest.mark.gpu
@@ -88,16 +153,19 @@ def test_cpp_multistart_host_equals_the_oracle_trace():
     out = "/tmp/weldacs_ms_%d.txt" % os.getpid()
     r = subprocess.run([EXE, str(n), str(ants), str(K), "all", out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    loc, glob = {}, {}
+    loc, glob, owner, owner_path = {}, {}, {}, None
     for line in open(out):
         t = line.split()
         if t[0] == "local":
             loc.setdefault(int(t[1]), {})[int(t[2])] = int(t[3], 16)
         elif t[0] == "global":
             glob[int(t[1])] = int(t[2], 16)
+            owner[int(t[1])] = (int(t[3]), int(t[4]))
+        elif t[0] == "owner_path":
+            owner_path = (int(t[1]), [int(v) for v in t[3:3 + int(t[2])]])
     W = len(loc)
     assert W >= 1 and len(glob) == K
-    hist = []
+    hist, best_paths = [], []
     for rk in range(W):
         og = O.synth_grid(n, seed=2024 + rk, occ_prob=0.10)
         free, *_ = synth.synth_grid(n, seed=2024 + rk, occ_prob=0.10)
@@ -107,4 +175,9 @@ def test_cpp_multistart_host_equals_the_oracle_trace():
         tr = a.solve(sid, eid, K, float(np.float32(ants / 0.35)), fixed_colony=ants, mode=O.DEV, seed=12345 + rk, stream=rk)
         assert [loc[rk][g] for g in range(K)] == bits(tr["bestL"]).tolist(), rk
         hist.append(tr["bestL"])
-    assert [glob[g] for g in range(K)] == bits(np.min(np.stack(hist), 0)).tolist()
+        best_paths.append(a.best_path()[0])
+    H = np.stack(hist)
+    assert [glob[g] for g in range(K)] == bits(np.min(H, 0)).tolist()
+    # the owner the packed key carries: the lowest rank among those that hold the minimum, slot 0; and its path reached rank 0
+    assert [owner[g] for g in range(K)] == [(int(np.argmin(H[:, g])), 0) for g in range(K)]
+    assert owner_path is not None and owner_path[0] == owner[K - 1][0] and owner_path[1] == best_paths[owner_path[0]].tolist()

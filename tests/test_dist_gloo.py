@@ -19,7 +19,7 @@ WORKER = textwrap.dedent("""
     import json, os, sys
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
-    from welding_robot_amd import dist as wd
+    from welding_robot_amd import dist as wd, api
     rank, local_rank, world = wd.env_rank()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
@@ -35,8 +35,17 @@ WORKER = textwrap.dedent("""
         w.wait()
         glob.append(t.numpy())
     glob = np.concatenate(glob)
+    # the owner-carrying exchange (csrc/host_comm.inc: one MIN all-reduce of the packed key): keys packed by the library's own helper,
+    # reduced over gloo as int64 (non-negative float bits keep the top bit clear), unpacked again
+    slots = 3
+    local = np.stack([np.roll(trace, q) for q in range(slots)])          # this rank's searches
+    local[:, :5] = np.float32(777.0)                                     # ties across ranks AND slots in the first generations
+    keys = torch.tensor([min(api.pack_best_key(float(local[q, g]), rank, q) for q in range(slots)) for g in range(K)], dtype=torch.int64)
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+    owners = [api.unpack_best_key(int(k)) for k in keys.tolist()]
     elapsed = 0.010 * (rank + 1)
-    out = dict(rank=rank, world=world, mine=trace.tolist(), glob=glob.tolist(),
+    out = dict(rank=rank, world=world, mine=trace.tolist(), glob=glob.tolist(), local=local.tolist(),
+               owners=[[float(c), r, q] for c, r, q in owners],
                tmax=wd.max_over_ranks(elapsed, dev), total=wd.sum_over_ranks(K, dev),
                shard=wd.shard_problems(2016, rank, world), wl=wd.per_rank_workload(rank))
     json.dump(out, open(sys.argv[1] + ".%%d" %% rank, "w"))
@@ -68,10 +77,38 @@ def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     for r in res:
         assert np.array_equal(np.array(r["glob"], np.float32), want)  # global best per generation = MIN over ranks
         assert r["tmax"] == 0.020 and r["total"] == 260 and r["world"] == 2
+    # packed keys: every rank sees the same (cost, owner rank, owner slot) per generation = the lexicographic minimum over all searches
+    allloc = np.stack([np.array(r["local"], np.float32) for r in res])          # [rank][slot][generation]
+    for g in range(allloc.shape[2]):
+        cands = sorted((float(allloc[r, q, g]), r, q) for r in range(2) for q in range(allloc.shape[1]))
+        assert res[0]["owners"][g] == res[1]["owners"][g] == list(cands[0]), g
+    assert res[0]["owners"][0] == [777.0, 0, 0]                                 # a tie goes to the lowest rank, then the lowest slot
     assert wd.aggregate_rate(res[0]["total"], res[0]["tmax"]) == 260 / 0.020
     a, b = set(res[0]["shard"]), set(res[1]["shard"])
     assert not (a & b) and a | b == set(range(2016)) and abs(len(a) - len(b)) <= 1
     assert res[0]["wl"] != res[1]["wl"] and res[1]["wl"]["grid_seed"] == 2025 and res[1]["wl"]["rng_seed"] == 12346
+
+
+def test_comm_id_is_shipped_over_a_socket_without_torch(tmp_path):
+    """wd.ship_unique_id: rank 0 hands the 128 bytes of a wa_comm id to the other ranks (examples/plan_batch.py under torchrun);
+    three processes, the late ones retry until rank 0 listens"""
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        from welding_robot_amd import dist as wd
+        rank, world, port = int(sys.argv[1]), 3, int(sys.argv[2])
+        if rank == 0:
+            time.sleep(0.5)                       # the others are already knocking
+        uid = wd.ship_unique_id(rank, world, lambda: bytes(range(128)), port=port, addr="127.0.0.1", timeout_s=60)
+        assert uid == bytes(range(128)), uid
+    """) % ROOT
+    script = tmp_path / "ship.py"
+    script.write_text(code)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port)]) for r in (1, 2, 0)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    assert wd.ship_unique_id(0, 1, lambda: b"x" * 128) == b"x" * 128
 
 
 def test_single_process_helpers_are_identity():

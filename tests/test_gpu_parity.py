@@ -504,6 +504,29 @@ def test_batched_pair_planning_matches_oracle_and_is_shard_invariant(ctx):
     assert t["L"][0] == o["L"] and np.array_equal(t["edges"][0], o["edges"])
 
 
+def test_pair_planning_with_the_library_collectives_equals_the_plain_run(tmp_path):
+    """examples/plan_batch.py as a process: with WA_FORCE_DIST=1 the end-of-run exchanges of a multi-process run (wa_comm_allgather_costs,
+    wa_comm_gather_paths; RCCL behind the C ABI, id shipped over a socket, no torch) are issued over the world of one rank; matrix, tour
+    and the stitched + smoothed trajectory must be those of the plain single-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(G), "..")
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, WA_FORCE_DIST=force)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "plan_batch.py"), "--grid", "40", "--points", "7", "--generations", "40", "--slots", "4"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = outs
+    assert a["all_reached"] and b["all_reached"] and a["stitched_nodes"] > 0
+    for k in ("tour_cost", "tour_iterations", "order", "stitched_nodes", "coarse_points", "trajectory_samples", "trajectory_length"):
+        assert a[k] == b[k], k
+
+
 def test_best_path_replay_is_bit_identical_to_full_steps_at_full_size(ctx):
     """C3 (128^3, 256 ants), 260 generations -- long past convergence, where nearly every step is a
     replay step: the replay shortcut (WA_REPLAY=1, default) and the plain step loop (WA_REPLAY=0) must

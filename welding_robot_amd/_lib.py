@@ -86,6 +86,12 @@ SYMBOLS = {
     "wa_comm_info": (C.c_int, [_V, _P, _P]),
     "wa_acs_allreduce_best": (C.c_int, [_V, _V, _I, _I]),
     "wa_comm_read_best": (C.c_int, [_V, _I, _I, _P]),
+    "wa_comm_read_best_owner": (C.c_int, [_V, _I, _I, _P, _P, _P]),
+    "wa_comm_pack_best_key": (C.c_int, [_F, _I, _I, _P]),
+    "wa_comm_unpack_best_key": (C.c_int, [C.c_uint64, _P, _P, _P]),
+    "wa_comm_allgather_costs": (C.c_int, [_V, _I, _P, _P, _I, _P]),
+    "wa_comm_gather_paths": (C.c_int, [_V, _I, _I, _P, _P, _P, _P, _P]),
+    "wa_comm_gathered_paths_read": (C.c_int, [_V, _P, _P, _P]),
     "wa_comm_allreduce_f64": (C.c_int, [_V, _P, _I, _I]),
     "wa_comm_barrier": (C.c_int, [_V]),
     "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),

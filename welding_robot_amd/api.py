@@ -315,6 +315,21 @@ def straggler_pool_bytes(grid, n_slots, max_colony, path_capacity=0, neighbourho
     return b.value
 
 
+def pack_best_key(cost, rank, slot, lib_path=None):
+    """the 64-bit key of the global-best exchange (host-side helper of the library: cost bits << 32 | rank << 16 | slot)"""
+    k = C.c_uint64()
+    rc = L.load(lib_path).wa_comm_pack_best_key(C.c_float(cost), rank, slot, C.byref(k))
+    if rc:
+        raise WeldacsError(rc, "wa_comm_pack_best_key")
+    return k.value
+
+
+def unpack_best_key(key, lib_path=None):
+    c, r, s_ = C.c_float(), C.c_int32(), C.c_int32()
+    L.load(lib_path).wa_comm_unpack_best_key(C.c_uint64(int(key)), C.byref(c), C.byref(r), C.byref(s_))
+    return np.float32(c.value), r.value, s_.value
+
+
 def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True):
     """Concurrent pair searches for `n_pairs` searches on this device -- the rule of the drop-in ACS_Rank::slots_for
     (welding_robot_amd/include/core/ACSRank_3D.hpp): 3/4 of the free memory but at most ~200 GB of fields, at most three
@@ -366,6 +381,36 @@ class Comm:
         out = np.empty(count, np.float32)
         self.ctx.check(self.ctx.lib.wa_comm_read_best(self.h, gen0, count, _ptr(out)))
         return out
+
+    def read_best_owner(self, gen0, count):
+        """(global best cost, owner rank, owner slot) per generation: whose search holds the path that achieved it"""
+        cost, rk, sl = np.empty(count, np.float32), np.empty(count, np.int32), np.empty(count, np.int32)
+        self.ctx.check(self.ctx.lib.wa_comm_read_best_owner(self.h, gen0, count, _ptr(cost), _ptr(rk), _ptr(sl)))
+        return cost, rk, sl
+
+    def allgather_costs(self, index, cost, n_total, fill=np.nan):
+        """every rank's (pair index, cost) records to every rank: a vector of n_total costs (entries nobody owns = fill)"""
+        index = np.ascontiguousarray(index, np.int32)
+        cost = np.ascontiguousarray(cost, np.float32)
+        assert index.shape == cost.shape
+        out = np.full(n_total, fill, np.float32)
+        self.ctx.check(self.ctx.lib.wa_comm_allgather_costs(self.h, index.size, _ptr(index), _ptr(cost), n_total, _ptr(out)))
+        return out
+
+    def gather_paths(self, paths, root=0):
+        """paths: {global index: node ids} of this rank.  On `root`: {index: ids} of ALL ranks; elsewhere {}."""
+        keys = list(paths)
+        index = np.ascontiguousarray(keys, np.int32)
+        lens = np.ascontiguousarray([len(paths[k]) for k in keys], np.int64)
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(paths[k], np.int32) for k in keys]) if keys else np.zeros(0), np.int32)
+        npaths, nids = C.c_int64(), C.c_int64()
+        self.ctx.check(self.ctx.lib.wa_comm_gather_paths(self.h, root, index.size, _ptr(index), _ptr(lens), _ptr(ids), C.byref(npaths), C.byref(nids)))
+        if self.rank != root:
+            return {}
+        gi, gl, gd = np.empty(npaths.value, np.int32), np.empty(npaths.value, np.int64), np.empty(nids.value, np.int32)
+        self.ctx.check(self.ctx.lib.wa_comm_gathered_paths_read(self.h, _ptr(gi), _ptr(gl), _ptr(gd)))
+        off = np.concatenate([[0], np.cumsum(gl)])
+        return {int(gi[i]): gd[off[i]:off[i + 1]].copy() for i in range(npaths.value)}
 
     def allreduce(self, values, op="max"):
         v = np.ascontiguousarray(np.atleast_1d(values), np.float64).copy()

@@ -34,6 +34,17 @@ def hipcc():
     return "hipcc"
 
 
+def rocm_lib_dir():
+    """where librccl / libamdhip64 of the chosen toolchain live: $ROCM_PATH/lib, else next to the hipcc in use"""
+    import shutil
+    root = os.environ.get("ROCM_PATH")
+    if not root:
+        exe = shutil.which(hipcc()) or hipcc()
+        root = os.path.dirname(os.path.dirname(os.path.realpath(exe)))
+    d = os.path.join(root, "lib")
+    return d if os.path.isdir(d) else "/opt/rocm/lib"
+
+
 def needs_build(lib=None):
     lib = lib or LIB_PATH
     if not os.path.exists(lib):
@@ -50,7 +61,9 @@ def build(force=False, verbose=False, extra=(), out=None):
     os.makedirs(LIB_DIR, exist_ok=True)
     out = out or LIB_PATH
     # librccl: the global-best all-reduce of the multi-GPU path (csrc/host_comm.inc) -- linked by the library itself
-    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-L/opt/rocm/lib", "-lrccl"]
+    # (found through the toolchain's own directory, which also becomes the library's run path: a ROCm outside /opt/rocm loads)
+    libdir = rocm_lib_dir()
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-L" + libdir, "-Wl,-rpath," + libdir, "-lrccl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -45,6 +45,47 @@ def deal_pairs(pairs, weights, world):
     return shards, load
 
 
+def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0):
+    """The 128-byte id of a wa_comm from rank 0 to the other ranks of one job without torch / MPI: rank 0 listens on
+    MASTER_ADDR : MASTER_PORT + 1000 and hands the bytes to world - 1 connections.  make_id() is only called on rank 0."""
+    import socket
+    import time
+    if world == 1:
+        return bytes(bytearray(make_id()))
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = port or int(os.environ.get("MASTER_PORT", "29500")) + 1000
+    if rank == 0:
+        uid = bytes(bytearray(make_id()))
+        srv = socket.socket()
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout_s)
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.sendall(uid)
+            c.close()
+        srv.close()
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout_s:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 128:
+        chunk = c.recv(128 - len(buf))
+        if not chunk:
+            raise RuntimeError("ship_unique_id: rank 0 closed the connection early")
+        buf += chunk
+    c.close()
+    return buf
+
+
 def per_rank_workload(rank, grid_seed=2024, rng_seed=12345):
     """C4: one independent 128^3 grid per GPU: grid seed 2024 + rank, colony seed 12345 + rank"""
     return dict(grid_seed=grid_seed + rank, rng_seed=rng_seed + rank, stream=rank)
