@@ -513,6 +513,7 @@ def main():
         done += c
     solver.sync()
     glob = comm.read_best(0, K) if comm is not None else None   # waits for the exchanges
+    owner = [int(v[0]) for v in comm.read_best_owner(K - 1, 1)[1:]] if comm is not None else None   # (rank, slot) that holds the final global best's path
     for w in works:
         if w is not None:
             w.wait()
@@ -606,7 +607,7 @@ def main():
                                       note="average over the STAMPED generations only (every %d-th of the timed region: hipEventRecord around each launch, which "
                                            "costs the stream ~8 us per stamp, so the sum exceeds ms_per_step); the unperturbed per-kernel times of this command are "
                                            "the rocprofv3 kernel stats under profiles/" % args.profile_every),
-            "stragglers": stragglers, "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
+            "global_best_owner": owner, "stragglers": stragglers, "setup_ms": setup_ms, "waited_for_device_memory_s": mem_wait_s, "best_cost": float(cost), "best_cost_all_ranks": best_all, "path_nodes": int(len(path)),
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
             "device": ctx.device_name,
         }

@@ -331,6 +331,11 @@ int wa_bspline_read(const wa_bspline *b, float *knots, float *cps /* n_cps x dim
  * leaves `ret` untouched). */
 int wa_bspline_eval(wa_bspline *b, const float *u, int64_t count, int32_t der, float *out /* count x dim */,
                     uint8_t *ok);
+/* ONE time, evaluated on the host from a mirror of the knots and control points (fetched once per SetParam) by the same fp32
+ * operations in the same order as the kernel: bit-identical to wa_bspline_eval, ~0.1-0.2 us per call instead of a launch +
+ * synchronise + copy.  What the drop-in BS_Basic::getCurvePoint / getCurveDerPoint use: main.cpp:302-316 / :341-351 call them once per
+ * sample inside clock()-paced loops whose sample count depends on how long a call takes.  out: dim floats (zeros when *ok = 0). */
+int wa_bspline_eval_host(wa_bspline *b, float u, int32_t der, float *out /* dim */, uint8_t *ok);
 /* fixed-rate sampling u_i = t0 + (float)i * dt (fp32), replacing main.cpp's clock()-paced loops
  * (:302-316, :341-351).  out / ok may be NULL; out_traj (may be NULL, needs dim == 3 and der == 0 or
  * any der) receives the samples as a device-resident polyline, e.g. as the next spline's middle points. */

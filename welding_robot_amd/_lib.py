@@ -108,6 +108,7 @@ SYMBOLS = {
     "wa_bspline_info": (C.c_int, [_V, _P, _P]),
     "wa_bspline_read": (C.c_int, [_V, _P, _P]),
     "wa_bspline_eval": (C.c_int, [_V, _P, _I64, _I, _P, _P]),
+    "wa_bspline_eval_host": (C.c_int, [_V, _F, _I, _P, _P]),
     "wa_bspline_sample": (C.c_int, [_V, _F, _F, _I64, _I, _P, _P, C.POINTER(_V)]),
 }
 

@@ -503,6 +503,13 @@ class Bspline:
         self.ctx.check(self.ctx.lib.wa_bspline_eval(self.h, _ptr(us), len(us), der, _ptr(out), _ptr(ok)))
         return out, ok
 
+    def eval_host(self, u, der=0):
+        """one time on the host (wa_bspline_eval_host): (dim values, ok)"""
+        out = np.zeros(self.dim, np.float32)
+        ok = C.c_uint8()
+        self.ctx.check(self.ctx.lib.wa_bspline_eval_host(self.h, C.c_float(u), der, _ptr(out), C.byref(ok)))
+        return out, bool(ok.value)
+
     def sample(self, t0, dt, count, der=0, host=True, device=False):
         out = np.empty((count, self.dim), np.float32) if host else None
         ok = np.empty(count, np.uint8) if host else None

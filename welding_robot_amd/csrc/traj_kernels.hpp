@@ -49,7 +49,7 @@ __global__ void k_stitch(const long long *__restrict__ ids, const long long *__r
 
 // ---------------------------------------------------------------- BS_Basic pieces
 // _findSpan (:358-385)
-__device__ __forceinline__ bool wa_bs_find_span(const float *K, long long nk, float u, long long *ret)
+__host__ __device__ inline bool wa_bs_find_span(const float *K, long long nk, float u, long long *ret)
 {
     float last = K[nk - 1];
     if (u < K[0] || last < u) return false;
@@ -72,7 +72,7 @@ __device__ __forceinline__ bool wa_bs_find_span(const float *K, long long nk, fl
 
 // _BasisFuns (:330-353)
 template <int DEG>
-__device__ __forceinline__ void wa_bs_basis_funs(const float *K, float *N, long long span, float u)
+__host__ __device__ __forceinline__ void wa_bs_basis_funs(const float *K, float *N, long long span, float u)
 {
     float left = 0.0f, right = 0.0f, saved = 0.0f, temp = 0.0f;
     N[0] = 1.0f;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void wa_bs_basis_funs(const float *K, float *N, long 
 }
 
 // _BasisFunsDers(ders, span, u, n) (:237-323); D is a run-time degree here (setup and derivative paths)
-__device__ void wa_bs_basis_ders(const float *K, int D, float uninit, float ders[][WA_BS_W + 2],
+__host__ __device__ inline void wa_bs_basis_ders(const float *K, int D, float uninit, float ders[][WA_BS_W + 2],
                                  long long span, float u, int n)
 {
     float ndu[WA_BS_W][WA_BS_W], a[2][WA_BS_W];
@@ -218,29 +218,23 @@ __global__ void k_bspline_middle(WaSpline S, const float *__restrict__ middle, l
     S.cps[(S.ci + 1 + i) * S.dim + m] = middle[i * stride + m];
 }
 
-// getCurvePoint (:87-112) / getCurveDerPoint (:122-146), one lane per time.  us == nullptr: u = t0 + i*dt.
-// Rows that the reference would refuse (span search fails, d > DEGREE) get ok = 0 and zeros.
+// getCurvePoint (:87-112) / getCurveDerPoint (:122-146) for ONE time u: dim values to `o`; false (and zeros) where the reference would
+// refuse (span search fails, d > DEGREE).  One definition for the kernel (one lane per time) and for the host path of single-point
+// calls (wa_bspline_eval_host: the same source compiled for the host with -ffp-contract=off, so the same fp32 operations in the same order).
 template <int DEG>
-__global__ void k_bspline_eval(WaSpline S, const float *__restrict__ us, float t0, float dt, long long count,
-                               int32_t der, float *__restrict__ out, uint8_t *__restrict__ ok)
+__host__ __device__ __forceinline__ bool wa_bs_eval_one(const WaSpline &S, const float *__restrict__ K, const float *__restrict__ C,
+                                                        float u, int32_t der, float *__restrict__ o)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float *__restrict__ K = S.knots;
-    const float *__restrict__ C = S.cps;
     const int dim = S.dim;
-    float u = us ? us[i] : t0 + (float)i * dt;
     float lastk = K[S.n_knots - 1];
     if (u < K[0]) u = K[0];
     else if (u > lastk) u = lastk;
     long long span = 0;
     bool good = der <= DEG && wa_bs_find_span(K, S.n_knots, u, &span);
     good = good && span - DEG >= 0 && span < S.n_cps && span + DEG < S.n_knots;
-    float *o = out + i * dim;
     if (!good) {
         for (int m = 0; m < dim; ++m) o[m] = 0.0f;
-        if (ok) ok[i] = 0;
-        return;
+        return false;
     }
     if (der == 0) {
         float N[DEG + 1];
@@ -262,5 +256,17 @@ __global__ void k_bspline_eval(WaSpline S, const float *__restrict__ us, float t
             o[m] = c;
         }
     }
-    if (ok) ok[i] = 1;
+    return true;
+}
+
+// one lane per time.  us == nullptr: u = t0 + i*dt.
+template <int DEG>
+__global__ void k_bspline_eval(WaSpline S, const float *__restrict__ us, float t0, float dt, long long count,
+                               int32_t der, float *__restrict__ out, uint8_t *__restrict__ ok)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float u = us ? us[i] : t0 + (float)i * dt;
+    const bool good = wa_bs_eval_one<DEG>(S, S.knots, S.cps, u, der, out + i * S.dim);
+    if (ok) ok[i] = good ? 1 : 0;
 }

@@ -48,6 +48,9 @@ struct wa_bspline {
     WaSpline S;            // knots / cps on the device
     float *d_ends;         // init rows + fin rows staged for k_bspline_setup
     bool set;
+    // host mirror of knots / control points for single-point calls (wa_bspline_eval_host): fetched on the first such call after SetParam
+    std::vector<float> h_knots, h_cps;
+    bool h_valid = false;
 };
 struct EvPair { hipEvent_t a, b; int cls; };
 struct wa_acs {

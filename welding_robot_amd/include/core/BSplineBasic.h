@@ -10,6 +10,10 @@
 //  * BS_Basic<float,3,2,2,2> (main.cpp:337) makes the reference read two never-written heap cells
 //    (c_mat[idx][CONST_LEVEL_FIN+1], BSplineBasic.h:414-431); that value is explicit here:
 //    setUninitializedValue(v), default 0;
+//  * getCurvePoint / getCurveDerPoint evaluate ONE time on the host (wa_bspline_eval_host: knots and control points are mirrored
+//    once per SetParam; same fp32 operations in the same order as the kernel, bit-identical, ~0.1-0.2 us per call), because
+//    main.cpp:302-316 / :341-351 call them inside clock()-paced loops whose sample count depends on the call's duration;
+//    setHostEvaluation(false) sends every call through the device instead (a launch + synchronise + copy each);
 //  * sample(t0, dt, count, out) evaluates a whole fixed-rate time series in one launch -- the replacement
 //    for main.cpp's clock()-paced loops (:302-316, :341-351), whose sample count depends on CPU speed;
 //  * the destructor frees the device arrays (the reference leaks Knots_ / CPoints_).
@@ -30,7 +34,7 @@ class BS_Basic {
     static_assert(std::is_same<T, float>::value, "libweldacs evaluates BS_Basic in fp32 only");
 
 public:
-    BS_Basic(int _NUM_MIDDLE) : h_(NULL), status_(WA_OK), num_middle_(_NUM_MIDDLE)
+    BS_Basic(int _NUM_MIDDLE) : h_(NULL), status_(WA_OK), num_middle_(_NUM_MIDDLE), host_eval_(true)
     {
         wa_ctx *ctx = weldacs_dropin::context();
         if (!ctx) { status_ = WA_ERR_DEVICE; return; }
@@ -76,6 +80,7 @@ public:
         memcpy(&b, &v, 4);
         if (h_) wa_bspline_set_uninit(h_, b);
     }
+    void setHostEvaluation(bool on) { host_eval_ = on; }
     int lastStatus() const { return status_; }
     wa_bspline *handle() { return h_; }
 
@@ -85,7 +90,7 @@ private:
         if (!h_) return false;
         float out[DIM];
         uint8_t ok = 0;
-        status_ = wa_bspline_eval(h_, &u, 1, d, out, &ok);
+        status_ = host_eval_ ? wa_bspline_eval_host(h_, u, d, out, &ok) : wa_bspline_eval(h_, &u, 1, d, out, &ok);
         if (status_ != WA_OK || !ok) return false;      // `ret` untouched, as in the reference
         for (int i = 0; i < DIM; ++i) ret[i] = out[i];
         return true;
@@ -93,6 +98,7 @@ private:
     wa_bspline *h_;
     int status_;
     int num_middle_;
+    bool host_eval_;
 };
 
 #endif
