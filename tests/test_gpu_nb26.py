@@ -1,7 +1,15 @@
 """GPU parity for the 26-neighbour search variant (wa_acs_create_nb(..., 26)):
   REF mode against golden vectors produced by the reference's own selectNext / update_pheromone / Agent
   code running on 26-neighbour adjacency lists (tests/golden/make_golden.py nb26), bit-exact;
-  DEV mode against the C oracle's 26-neighbour mode, bit-exact (path ids, edge indices, every pheromone value)."""
+  DEV mode against the C oracle's 26-neighbour mode, bit-exact (path ids, edge indices, every pheromone value).
+
+What the REF goldens are and are not: the reference as SHIPPED never walks an edge or corner move -- initFromGridMap sets those two
+distances to 0, which skips them (ACSRank_3D.hpp:361-388), and its evaporation / reset loops are hard-wired to six entries (:270, :312).
+The goldens come from the HARNESS-WIDENED reference: oracle/ref_harness.cpp rebuilds the adjacency lists of the reference's own
+ACS_Node objects with 26 entries in the cube order of :352-388 (`widen_to_26`), gives the two extra move types the lengths the
+reference keeps in comments (precision * 1.414f, precision * 1.732f), restates the evaporation loop for 26 entries, and then drives the
+reference's unmodified selectNext / update_pheromone / Agent members.  That is the harness's reading of a variant the author stubbed
+out -- the right oracle for it, but not the reference as it stands; the 6-neighbour goldens are the reference as it stands."""
 import os
 
 import numpy as np

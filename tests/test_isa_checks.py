@@ -1,0 +1,65 @@
+"""CPU-side checks on the compiled device code (hipcc cross-compiles gfx950 without a GPU):
+ * tools/check_walk26_isa.py -- what the 26-neighbour fast loop relies on beyond the compiler's promises: inline-issued
+   loads waited for by a later statement, hard-coded touch registers;
+ * every diagnostic -D build the tools use still compiles (-DWA_STAMPS, -DWA_ANT_TIME, -DWA_STRAG_TIME, -DWA_ASM_STAMPS,
+   -DWA_ASM_SPAN_A/B), so the measurement tools cannot rot silently."""
+import importlib.util
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from welding_robot_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _checker():
+    spec = importlib.util.spec_from_file_location("check_walk26_isa", os.path.join(ROOT, "tools", "check_walk26_isa.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def device_asm():
+    return _checker().assemble()
+
+
+def test_walk26_loop_keeps_its_loads_and_registers_to_itself(device_asm):
+    chk = _checker()
+    problems, info = chk.check(device_asm)
+    assert not problems, problems
+    assert info["touch_loads"] >= 4 and info["deferred_pairs"] >= 1 and info["highest_own_vgpr"] < 200
+
+
+def test_walk26_checker_sees_what_it_is_there_for(device_asm):
+    """the checker on doctored code: the deferred wait removed, a copy of a freshly requested record, a stray use of a touch register"""
+    chk = _checker()
+    lines = device_asm.split("\n")
+    k0 = next(i for i, l in enumerate(lines) if l.startswith(chk.KERNEL + ":"))
+    k1 = next(i for i in range(k0, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[k0:k1]
+    w = [i for i, l in enumerate(body) if l.strip() == "s_waitcnt vmcnt(4)"]
+    assert w
+    no_wait = lines[:k0] + [("\ts_nop 0" if i in w else l) for i, l in enumerate(body)] + lines[k1:]
+    assert any("touched before their wait" in p for p in chk.check("\n".join(no_wait))[0])
+    t = next(i for i, l in enumerate(body) if "global_load_dword v250" in l)
+    stray = lines[:k0] + body[:t] + ["\tv_mov_b32_e32 v3, v251"] + body[t:] + lines[k1:]
+    assert any("outside the touch loads" in p for p in chk.check("\n".join(stray))[0])
+
+
+DIAG_BUILDS = [["-DWA_STAMPS"], ["-DWA_ANT_TIME"], ["-DWA_STRAG_TIME"], ["-DWA_ASM_STAMPS"], ["-DWA_ASM_SPAN_A=2", "-DWA_ASM_SPAN_B=5"],
+               ["-DWA_ASM_SPAN_A=10", "-DWA_ASM_SPAN_B=10"], ["-DWA_TEST_KNOBS", "-DWA_STAMPS"]]
+
+
+def test_every_diagnostic_build_compiles(tmp_path):
+    def one(defs):
+        out = str(tmp_path / ("lib_" + "_".join(d.strip("-D").replace("=", "") for d in defs) + ".so"))
+        r = subprocess.run([build.hipcc()] + build.FLAGS + defs + [os.path.join(build.CSRC, "weldacs.hip"), "-o", out, "-L" + build.rocm_lib_dir(), "-lrccl"],
+                           capture_output=True, text=True)
+        return defs, r.returncode, r.stderr[-1500:]
+    with ThreadPoolExecutor(3) as ex:
+        for defs, rc, err in ex.map(one, DIAG_BUILDS):
+            assert rc == 0, (defs, err)

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Build-time check of what the 26-neighbour fast loop (k_walk_dev26, acs_kernels.hpp) relies on but the compiler does not promise
+(ADVICE r03): its next-step record loads are ISSUED by one inline statement and WAITED for by a later one (`s_waitcnt vmcnt(4)`), and its
+touch loads land in v250..v253, which only the statement's clobber list names.  Checked on the assembled kernel:
+
+  1. v250..v253 appear in no instruction of the kernel other than the touch loads themselves;
+  2. from every record-load pair that is not waited for on the spot, along EVERY control-flow path, no instruction reads or writes the
+     two destination registers before an `s_waitcnt` with vmcnt <= 4 has been passed (no copy, no phi move, no spill in between);
+  3. apart from the clobbered v250..v253 the kernel's own registers stay far below them.
+
+    python tools/check_walk26_isa.py [file.s]        (no GPU needed; without a file the library's device code is assembled with hipcc -S)
+Exit status 0 and a one-line summary, or 1 and the offending instructions."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from welding_robot_amd import build  # noqa: E402
+
+KERNEL = "_Z12k_walk_dev268WaAcsDev5WaRuniii"
+TOUCH = {250, 251, 252, 253}
+
+
+def assemble():
+    asm = "/tmp/weldacs_walk26_%d.s" % os.getpid()
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([build.hipcc()] + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "weldacs.hip"), "-o", asm], stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    os.unlink(asm)
+    return text
+
+
+def vregs(operand_text):
+    """VGPR indices an operand string names: v12, v[8:11]"""
+    out = set()
+    for m in re.finditer(r"\bv(\d+)\b", operand_text):
+        out.add(int(m.group(1)))
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check(text):
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    ins, labels = [], {}
+    for l in lines[start + 1:end]:
+        t = l.split(";")[0].strip()
+        if not t or t.startswith((".", "//")) and not t.endswith(":"):
+            continue
+        if t.endswith(":"):
+            labels[t[:-1]] = len(ins)
+            continue
+        ins.append(t)
+    problems = []
+    # 1. the touch registers
+    touch_sites = 0
+    for i, t in enumerate(ins):
+        used = vregs(t.split(None, 1)[1] if " " in t else "")
+        if used & TOUCH:
+            if t.startswith("global_load_dword v25") and len(used & TOUCH) == 1:
+                touch_sites += 1
+            else:
+                problems.append("v250..v253 used outside the touch loads: [%d] %s" % (i, t))
+    if touch_sites == 0 or touch_sites % 4:
+        problems.append("expected groups of four touch loads, found %d" % touch_sites)
+    # 2. issue ... wait
+    def waits_vm(t, limit):
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", t)
+        return bool(m) and int(m.group(1)) <= limit
+    pairs = 0
+    for i in range(len(ins) - 1):
+        a, b = ins[i], ins[i + 1]
+        if not (a.startswith("global_load_dword v") and b.startswith("global_load_dword v")):
+            continue
+        ra, rb = vregs(a.split(",")[0]), vregs(b.split(",")[0])
+        if (ra | rb) & TOUCH or (i > 0 and ins[i - 1].startswith("global_load_dword v25")):
+            continue
+        if i + 2 < len(ins) and waits_vm(ins[i + 2], 0):
+            continue                                    # waited for on the spot (the loads in front of the loop)
+        regs = ra | rb
+        pairs += 1
+        seen, todo = set(), [i + 2]
+        while todo:
+            k = todo.pop()
+            while k < len(ins) and k not in seen:
+                seen.add(k)
+                t = ins[k]
+                if waits_vm(t, 4):
+                    break
+                op = t.split(None, 1)
+                if len(op) > 1 and vregs(op[1]) & regs:
+                    problems.append("records loaded at [%d] (v%s) touched before their wait: [%d] %s" % (i, sorted(regs), k, t))
+                    break
+                if t.startswith("s_endpgm"):
+                    break
+                m = re.match(r"s_c?branch\w*\s+(\S+)", t)
+                if m and m.group(1) in labels:
+                    todo.append(labels[m.group(1)])
+                    if t.startswith("s_branch"):
+                        break
+                k += 1
+    if pairs == 0:
+        problems.append("no record-load pair with a deferred wait found: has the loop changed?")
+    # 3. register budget
+    own = set()
+    for t in ins:
+        op = t.split(None, 1)
+        if len(op) > 1:
+            own |= vregs(op[1]) - TOUCH
+    top = max(own) if own else -1
+    if top >= 200:
+        problems.append("the kernel's own VGPRs reach v%d: too close to the hard-coded touch registers" % top)
+    return problems, dict(instructions=len(ins), deferred_pairs=pairs, touch_loads=touch_sites, highest_own_vgpr=top)
+
+
+def main():
+    text = open(sys.argv[1]).read() if len(sys.argv) > 1 else assemble()
+    problems, info = check(text)
+    if problems:
+        print("k_walk_dev26 ISA check FAILED:")
+        for p in problems:
+            print("  " + p)
+        return 1
+    print("k_walk_dev26 ISA check ok: %(instructions)d instructions, %(deferred_pairs)d record-load pairs with a deferred wait, "
+          "%(touch_loads)d touch loads in v250..v253, highest VGPR of its own v%(highest_own_vgpr)d" % info)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
