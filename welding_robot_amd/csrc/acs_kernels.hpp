@@ -857,7 +857,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
     const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
     bool use_asm = false;
 #ifndef WA_STAMPS
-    use_asm = MODE == 1 && ALPHA1 && (walk_flags & 1);
+    use_asm = ALPHA1 && (walk_flags & 1) && (MODE == 1 || !SPARSE);   // (REF mode: the same loop, draws from the libc stream)
 #endif
     // ---- a straggler (the loop left through its check, st.reason == 5): its path so far goes to a pool entry of its generation; agents[]
     // says "not arrived, st.len nodes" (what the ranking sees); a resume block of the next walk launch finishes it and adds the rest to
@@ -982,6 +982,12 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 #endif
         if (!st.done && st.reason == 5 && hand_over()) return;
         if (!st.done) st.L = D.ltab[st.len - 1];                  // the generic loop goes on adding to it (also behind a full pool)
+    } else if (st.len < fast_limit && use_asm && MODE == 0) {
+        // REF mode on the hand-scheduled loop: draws from the shared libc stream, 64 at a time (wa_walk_fast_asm<..., REFDRAW>); whatever
+        // it leaves undone -- a dead end to be decided, a walk past the table's load limit -- the generic loop below finishes
+        wa_walk_fast_asm<0, WARM, true>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+                                        D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, nullptr, 0, 0, nullptr, 0x7fffffff,
+                                        &rng_rs, &rng_f, &rng_b);
     } else if (st.len < fast_limit && use_asm) {
         WA_PHASE(8);
         wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
@@ -1251,7 +1257,8 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
 
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
 // from the shared glibc stream in exactly the reference's order (:252-261)
-__global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)
+// walk_flags bit 0 (and alpha == 1): the hand-scheduled loop with draws from the libc stream, 64 at a time (walk_loop_gfx950.hpp, REFDRAW)
+__global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
     const int32_t slot = blockIdx.y;
@@ -1263,8 +1270,13 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t r = threadIdx.x < 31 ? D.rng->r[threadIdx.x] : 0;   // lane j holds word j of the state (see wa_glibc_next_lanes)
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
-    for (int32_t ant = 0; ant < colony; ant++)
-        wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);
+    if (R.alpha == 1 && (walk_flags & 1)) {
+        for (int32_t ant = 0; ant < colony; ant++)
+            wa_walk_one<0, true, false, true, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 1, 0u, heur_slot);
+    } else {
+        for (int32_t ant = 0; ant < colony; ant++)
+            wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);
+    }
     if (threadIdx.x < 31) D.rng->r[threadIdx.x] = r;
     if (threadIdx.x == 0) {
         D.rng->f = f;

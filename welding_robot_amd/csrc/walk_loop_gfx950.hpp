@@ -649,11 +649,84 @@
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [stamp] "s"(stamp_b), [markb] "s"(mark) \
         : "v96", "v97", "v98", "v99", "s33", "s34", "s35", "s36", "s37", "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 
+// ---- REF mode on the hand-scheduled loop: the shared libc stream, 64 draws at a time.
+// glibc TYPE_3 (random_r.c): r[f] += r[b], result r[f] >> 1, b = f - 3 (mod 31).  The walking wavefront keeps the state ROTATED so that the
+// front word is lane 0 (lane j = r[(f + j) % 31]); the COUNT next outputs are then one fully unrolled pass with compile-time indices --
+// 31 v_readlane into scalar registers, one s_add + one s_lshr + one v_writelane per output, 31 v_writelane back (rotated by COUNT so
+// that the new front is lane 0 again): ~4 instructions per draw instead of the ~12 of one wa_glibc_next_lanes call per step, and none
+// of them on the step's dependency chain.  Output n goes to lane LANE0 + n of `ub` as (float)r / 2^31 (ACSRank_3D.hpp:169).
+// lane LANE (a constant) of v := a wave-uniform value (scalar data operand, immediate lane select: no wait states needed)
+template <int LANE>
+__device__ __forceinline__ int32_t wa_writelane_imm(int32_t v, int32_t val_uniform)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val_uniform), "n"(LANE));
+    return v;
+}
+template <int COUNT, int LANE0, int N = 0>
+struct WaGlibcUnroll {
+    static __device__ __forceinline__ void out(uint32_t (&r)[31], int32_t &raw)
+    {
+        constexpr int i = N % 31;
+        r[i] += r[(i + 28) % 31];
+        raw = wa_writelane_imm<LANE0 + N>(raw, (int32_t)(r[i] >> 1));
+        WaGlibcUnroll<COUNT, LANE0, N + 1>::out(r, raw);
+    }
+    static __device__ __forceinline__ void back(const uint32_t (&r)[31], int32_t &rot)
+    {
+        if (N < 31) {
+            rot = wa_writelane_imm<(N < 31 ? N : 0)>(rot, (int32_t)r[(N + COUNT) % 31]);
+            WaGlibcUnroll<COUNT, LANE0, N + 1>::back(r, rot);
+        }
+    }
+};
+template <int COUNT, int LANE0>
+struct WaGlibcUnroll<COUNT, LANE0, COUNT> {
+    static __device__ __forceinline__ void out(uint32_t (&)[31], int32_t &) {}
+    static __device__ __forceinline__ void back(const uint32_t (&r)[31], int32_t &rot)
+    {
+        if (COUNT < 31) {
+            rot = wa_writelane_imm<(COUNT < 31 ? COUNT : 0)>(rot, (int32_t)r[(COUNT + COUNT) % 31]);
+        }
+    }
+};
+template <int COUNT, int LANE0>
+__device__ __forceinline__ void wa_glibc_block(int32_t &rot, float &ub)
+{
+    uint32_t r[31];
+#pragma unroll
+    for (int j = 0; j < 31; j++) r[j] = (uint32_t)__builtin_amdgcn_readlane(rot, j);
+    int32_t raw = 0;
+    WaGlibcUnroll<COUNT, LANE0>::out(r, raw);
+    WaGlibcUnroll<COUNT, LANE0>::back(r, rot);
+    static_assert(COUNT >= 31, "the write-back recursion covers lanes 0..30 only when COUNT >= 31");
+    ub = (float)raw / 2147483648.0f;
+}
+// canonical state (lane j = r[j], indices f, b) -> rotated / back
+__device__ __forceinline__ int32_t wa_glibc_rotate(int32_t rs, int32_t f)
+{
+    const int lane = threadIdx.x;
+    int src = f + lane;
+    src = src >= 31 ? src - 31 : src;
+    return lane < 31 ? __builtin_amdgcn_ds_bpermute(src * 4, rs) : 0;
+}
+__device__ __forceinline__ int32_t wa_glibc_unrotate(int32_t rot, int32_t f)
+{
+    const int lane = threadIdx.x;
+    int src = lane - f;
+    src = src < 0 ? src + 31 : src;
+    return lane < 31 ? __builtin_amdgcn_ds_bpermute(src * 4, rot) : 0;
+}
+
 // VARIANT 0: dense field.  1 (LAZY): the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the
 // slot's stamp array, clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far.
 // 2: dense field + rejoin watch (3: lazy field + rejoin watch): `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
 // st.reason = 4 when the loop handed back because the ant stood on the best path one step ago.
-template <int VARIANT, bool WARM = true>
+// REFDRAW (REF mode, dense field): the draws come from the libc stream (rng_rs / rng_f / rng_b, canonical form) instead of the counter hash.
+// The loop only knows how to hash its next 64 draws, so it is given ONE block at a time: its limit is the end of the current block, it
+// hands back at every block boundary (code 0, the block stored), the next 64 draws are generated here and it re-enters (its prologue
+// re-requests the records: ~1 us per 64 steps).  A dead end is handed to the caller's generic loop undecided: the reference only calls
+// rand() when a candidate exists (:162-166), and the loop's single exit does not say which of the two dead ends it met.
+template <int VARIANT, bool WARM = true, bool REFDRAW = false>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
                                                  int32_t *path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
@@ -661,7 +734,8 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                                                  int32_t guard_bytes, int32_t stamp_guard_bytes, const float *__restrict__ ltab, WaWalkState &st,
                                                  int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg,
                                                  const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0,
-                                                 const uint32_t *cut_list = nullptr, int32_t cut_n = 0x7fffffff)
+                                                 const uint32_t *cut_list = nullptr, int32_t cut_n = 0x7fffffff,
+                                                 int32_t *rng_rs = nullptr, int32_t *rng_f = nullptr, int32_t *rng_b = nullptr)
 {
     if (!cut_list) cut_n = 0x7fffffff;   // straggler check off (see WA_ASM_CUT); st.reason = 5 when the ant left through it
     cut_n = __builtin_amdgcn_readfirstlane(cut_n);   // (an SGPR operand of the loop: neither a literal nor a lane value)
@@ -672,7 +746,8 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     // lane block b = lane >> 3 fetches the record of neighbour 5 - b: the block that becomes active after a move is
     // then the POSITION of the picked lane (edge k sits at position 5 - k), one s_lshl away from the pick
     const int32_t dk = wa_delta(k2, nx, nxy), dj = wa_delta(j < 6 ? 5 - j : 5, nx, nxy);
-    const int32_t limit = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
+    const int32_t limit_full = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
+    int32_t limit = limit_full;   // (REFDRAW: the end of the current block, see below)
     const int32_t table = 1 << hash_log2;
     // field bases moved back by the guard band: every offset the loop forms is then non-negative
     const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
@@ -699,7 +774,23 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     if (REJOIN && st.pbuf_valid) pbuf = st.pbuf;
     else if (prefix_words)   // (through L2: the words may have been stored by this very wavefront a moment ago)
         pbuf = lane < (st.len & 63) ? __hip_atomic_load(&prefix_words[(st.len & ~63) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    float ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
+    float ublock = 0.f;
+    // REFDRAW: rot = the stream's state (rotated) behind the draws generated so far, rot_bs / len_bs = the same at the start of the
+    // block the ant is in -- the canonical state handed back is that one advanced by the draws the ant really consumed
+    int32_t rot = 0, rot_bs = 0, len_bs = len, f_bs = 0;
+    if (REFDRAW) {
+        f_bs = __builtin_amdgcn_readfirstlane(*rng_f);
+        rot = rot_bs = wa_glibc_rotate(*rng_rs, f_bs);
+        if ((len & 63) == 1) wa_glibc_block<63, 1>(rot, ublock);      // the walk starts at node count 1: steps 0..62 <-> lanes 1..63
+        else {                                                      // (any other entry point: one draw per step, in order)
+            int32_t rs = *rng_rs, f = f_bs, b = *rng_b, raw = 0;
+            for (int q = len & 63; q < 64; q++) raw = wa_writelane(raw, wa_glibc_next_lanes(rs, f, b), q);
+            rot = wa_glibc_rotate(rs, f);
+            ublock = (float)raw / 2147483648.0f;
+        }
+    } else {
+        ublock = (float)wa_ctr_draw(antkey, (uint32_t)((len & ~63) + lane - 1)) / 2147483648.0f;
+    }
     float p = -0.f, h = 0.f;
     if (j == 0 && pos < 6) {
         const uint32_t boff = ((uint32_t)cur * 6u + (uint32_t)k2) * 4u;
@@ -712,7 +803,8 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on, 5 straggler
     for (;;) {
         // the loop checks its limits once per 64-step block (inside, when a block completes): only enter a block that fits entirely
-        if ((len | 63) + 1 > limit) { exit_code = 3; break; }
+        if ((len | 63) + 1 > limit_full) { exit_code = 3; break; }
+        if (REFDRAW) limit = (len | 63) + 1;
         int32_t code;
         if (REJOIN && !LAZY) {
             if (WARM) { WA_ASM_RUN_REJ(SELF) } else { WA_ASM_RUN_REJ(NONE) }
@@ -729,9 +821,27 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
             for (int i = 0; i < 6; i++) atomicAdd(&dbg[i], (unsigned long long)(uint32_t)lcs[(7 + i) * 64]);
         }
 #endif
-        if (code == 0) continue;   // stopped at a block boundary (the block is stored): the limit test above decides
+        if (code == 0) {           // stopped at a block boundary (the block is stored): the limit test above decides
+            if (REFDRAW) {         // ... and the next block's 64 draws come from the libc stream
+                f_bs += len - len_bs;
+                f_bs %= 31;
+                rot_bs = rot;
+                len_bs = len;
+                wa_glibc_block<64, 0>(rot, ublock);
+            }
+            continue;
+        }
         exit_code = code;
         break;
+    }
+    if (REFDRAW) {
+        // the stream continues behind the draws this ant consumed: one per step taken (a dead end met by the loop is re-evaluated by the
+        // caller's generic loop, draw included if there is one)
+        int32_t rs = wa_glibc_unrotate(rot_bs, f_bs), f = f_bs, b = f_bs + 28;
+        b = b >= 31 ? b - 31 : b;
+        for (int32_t q = len_bs; q < len; q++) (void)wa_glibc_next_lanes(rs, f, b);
+        *rng_rs = rs; *rng_f = f; *rng_b = b;
+        if (exit_code == 1) exit_code = 3;
     }
     st.reason = 0;
     if (exit_code == 4) {   // handed back by the rejoin watch, at the head of a step
@@ -741,7 +851,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         // stored over a block that whoever brought the walk here had already written.)
         if ((len & 63) == 0 && len != st.len) path[(len - 64) + lane] = pbuf;
         if (cur == end) exit_code = 2;                       // ... which had arrived (:182-186)
-        else if (len >= limit) exit_code = 3;
+        else if (len >= limit_full) exit_code = 3;
         else st.reason = 4;
     }
 #if defined(WA_ASM_STAMPS)
