@@ -1,4 +1,4 @@
-// Does the voxel ORDER of a search's field matter for a saturated walk launch?  2 048 wavefronts, each taking a
+// Does the voxel ORDER of a search's field matter for a saturated walk launch (profiles/HISTORY.md)?  2 048 wavefronts, each taking a
 // synthetic random lattice walk in its own 256^3 field of 24-byte records (as many fields as fit: 224 x 402 MB), every step loading
 // the six neighbours' records of the voxel it stands on (36 lanes x 4 B, like the walk loop) and waiting for them.  Address of
 // voxel (x, y, z): row-major (the product's layout: a step in z is 1.5 MB away, i.e. always another 2-MB page) or brick-major (16^3

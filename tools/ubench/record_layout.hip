@@ -1,4 +1,4 @@
-// What would 32-byte records buy a saturated walk launch?  Waves take synthetic lattice walks, each in its own field set
+// What would 32-byte records buy a saturated walk launch (profiles/HISTORY.md)?  Waves take synthetic lattice walks, each in its own field set
 // (as in tools/ubench/page_locality.hip), and every step load what the lazy walk loop loads for the six neighbours of the voxel:
 //   layout A (the product's): pheromone [N][6] floats, heuristic [N][6] floats (shared by 64 waves), stamp [N] u32  -- three arrays, 24-B records
 //   layout B: pheromone + stamp [N][8] (six values, the stamp, one pad), heuristic [N][8]                           -- two arrays, 32-B records

@@ -126,56 +126,74 @@ __device__ __forceinline__ int32_t wa_delta(int k, int32_t nx, int32_t nxy)
     return k == 0 ? -nxy : k == 1 ? -nx : k == 2 ? -1 : k == 3 ? 1 : k == 4 ? nx : nxy;
 }
 
+// offsets (dx, dy, dz) of edge k.  6 neighbours: the push order of ACSRank_3D.hpp:355-365 (z-1, y-1, x-1, x+1, y+1, z+1);
+// 26 neighbours: the reference's cube loop (:352-388) -- z offset outermost, then y, then x, centre skipped
+__device__ __forceinline__ void wa_off26(int k, int &dx, int &dy, int &dz)
+{
+    const int q = k < 13 ? k : k + 1;
+    dz = q / 9 - 1;
+    dy = (q / 3) % 3 - 1;
+    dx = q % 3 - 1;
+}
+template <int NB>
+__device__ __forceinline__ void wa_edge_offset(int k, int &dx, int &dy, int &dz)
+{
+    if (NB == 26) { wa_off26(k, dx, dy, dz); return; }
+    dx = k == 2 ? -1 : k == 3 ? 1 : 0;
+    dy = k == 1 ? -1 : k == 4 ? 1 : 0;
+    dz = k == 0 ? -1 : k == 5 ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ pheromone init / reset
 // mode 0: initFromGridMap (out-of-bounds edges 0), mode 1: reset() (every edge pheromone_0).
-// The sign bit is set on edges whose neighbour is out of bounds or occupied.
+// The sign bit is set on edges whose neighbour is out of bounds or occupied.  Thread per (voxel, edge): coalesced 4-byte stores
+// over the [N][NB] field, one definition for both neighbourhoods.
+template <int NB>
 __global__ __launch_bounds__(256) void k_init_pheromone(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
 {
-    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= D.d.n) return;
-    int32_t slot = slot0 + blockIdx.y;
-    int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    float *p = D.pher + (int64_t)slot * D.pher_stride + id * 6;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
-                Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
-        bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
-        bool adm = inb && D.occ[id + wa_delta(k, D.d.nx, D.d.nxy)] != 0;
-        float v = (inb || mode == 1) ? p0 : 0.f;
-        p[k] = adm ? v : -v;
-    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= D.d.n * NB) return;
+    const int32_t slot = slot0 + blockIdx.y;
+    const int64_t id = t / NB;
+    const int k = (int)(t - id * NB);
+    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    int dx, dy, dz;
+    wa_edge_offset<NB>(k, dx, dy, dz);
+    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+    const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
+    const bool adm = inb && D.occ[id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
+    const float v = (inb || mode == 1) ? p0 : 0.f;
+    D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
 }
 
 // ------------------------------------------------------------------ heuristic field
 // (1 + beta*cos) of :151-154 is a function of the voxel, the edge and the END point only: the fields live in a pool,
 // wa_acs_begin computes one per distinct end point of its batch that the pool does not hold yet (`fields` / `ends` = pool
 // index and end point of each field to compute) and every search reads the field ctl.heur_slot names
+template <int NB>
 __global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta, const int32_t *fields, const int32_t *ends)
 {
-    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= D.d.n) return;
-    int32_t slot = fields[blockIdx.y];
-    int32_t end = ends[blockIdx.y];
-    int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
-    float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
-    float na = sqrtf(ax * ax + ay * ay + az * az);
-    float *h = D.heur + (int64_t)slot * D.pher_stride + id * 6;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
-                Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
-        float out = 0.f;
-        if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
-            float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];  // :151
-            float dot = ax * bx + ay * by + az * bz;
-            float nb = sqrtf(bx * bx + by * by + bz * bz);
-            float c = dot / (na * nb);  // :152 (0/0 = NaN on a duplicated seam coordinate, Q3)
-            out = 1 + beta * c;         // :154
-        }
-        h[k] = out;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= D.d.n * NB) return;
+    const int32_t slot = fields[blockIdx.y];
+    const int64_t id = t / NB;
+    const int k = (int)(t - id * NB);
+    const int32_t end = ends[blockIdx.y];
+    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
+    const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
+    int dx, dy, dz;
+    wa_edge_offset<NB>(k, dx, dy, dz);
+    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+    float out = 0.f;
+    if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+        const float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
+        const float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];     // :151
+        const float dot = ax * bx + ay * by + az * bz;
+        const float na = sqrtf(ax * ax + ay * ay + az * az);
+        const float nb = sqrtf(bx * bx + by * by + bz * bz);
+        out = 1 + beta * (dot / (na * nb));   // :152-154 (0/0 = NaN on a duplicated seam coordinate, Q3)
     }
+    D.heur[(int64_t)slot * D.pher_stride + t] = out;
 }
 
 // :247-249 -- colony in double then truncated, lambda double -> float, Q float
@@ -899,7 +917,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         return true;
     };
     if (REJ && st.len < fast_limit && use_asm && prefix_words && (walk_flags & 2)) {
-        // The ant replayed a prefix of the best path and left it.  Measured: such an ant is back on the path after a
+        // The ant replayed a prefix of the best path and left it.  Measured (profiles/HISTORY.md): such an ant is back on the path after a
         // median of 3-4 steps and 82-92 % of its remaining nodes lie on it, so the general loop runs with a rejoin watch and every
         // time the ant is found on the path again it goes back onto the replay track for as long as the table applies to it.
         const uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
@@ -1946,57 +1964,6 @@ __global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, WaRun R, i
 // One wavefront per ant, lane k < 26 owns neighbour k: LDS hash tabu with bitmap spill, ordered sums as
 // whole-wave DPP chains, cache-warming loads for the next step's records, best-path replay (k_replay_table26).
 // =====================================================================================================
-__device__ __forceinline__ void wa_off26(int k, int &dx, int &dy, int &dz)
-{
-    const int q = k < 13 ? k : k + 1;
-    dz = q / 9 - 1;
-    dy = (q / 3) % 3 - 1;
-    dx = q % 3 - 1;
-}
-
-// thread per (voxel, edge): coalesced 4-B stores over the [N][26] field
-__global__ __launch_bounds__(256) void k_init_pheromone26(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= D.d.n * 26) return;
-    const int32_t slot = slot0 + blockIdx.y;
-    const int64_t id = t / 26;
-    const int k = (int)(t - id * 26);
-    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    int dx, dy, dz;
-    wa_off26(k, dx, dy, dz);
-    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
-    const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
-    const bool adm = inb && D.occ[id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
-    const float v = (inb || mode == 1) ? p0 : 0.f;
-    D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
-}
-
-__global__ __launch_bounds__(256) void k_heuristic26(WaAcsDev D, float beta, const int32_t *fields, const int32_t *ends)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= D.d.n * 26) return;
-    const int32_t slot = fields[blockIdx.y];
-    const int64_t id = t / 26;
-    const int k = (int)(t - id * 26);
-    const int32_t end = ends[blockIdx.y];
-    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
-    int dx, dy, dz;
-    wa_off26(k, dx, dy, dz);
-    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
-    float out = 0.f;
-    if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
-        const float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
-        const float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];     // :151
-        const float dot = ax * bx + ay * by + az * bz;
-        const float na = sqrtf(ax * ax + ay * ay + az * az);
-        const float nb = sqrtf(bx * bx + by * by + bz * bz);
-        out = 1 + beta * (dot / (na * nb));                                                      // :152-154
-    }
-    D.heur[(int64_t)slot * D.pher_stride + t] = out;
-}
-
 // ---- best-path replay for the 26-neighbour walk: same idea as wa_walk_replay / k_replay_table.
 // Row of best-path node i = 32 floats: thr[26] (admissible ? prob_sum : -inf), total, edge taken to best[i+1],
 // L accumulated on arrival at node i (the in-order sum of the step lengths, which differ per move type here), pad.
