@@ -63,3 +63,17 @@ def test_every_diagnostic_build_compiles(tmp_path):
     with ThreadPoolExecutor(3) as ex:
         for defs, rc, err in ex.map(one, DIAG_BUILDS):
             assert rc == 0, (defs, err)
+
+
+def test_every_tool_and_example_script_still_compiles():
+    """tools/ and examples/ are not exercised by the suites one by one: at least they must parse and name no missing module of the package"""
+    import ast
+    import glob
+    import importlib
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "examples", "*.py"))):
+        tree = ast.parse(open(f).read(), f)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("welding_robot_amd"):
+                mod = importlib.import_module(node.module)
+                for a in node.names:
+                    assert hasattr(mod, a.name) or importlib.util.find_spec(node.module + "." + a.name), (f, node.module, a.name)

@@ -2,6 +2,7 @@
 """Per-ant block time against step count (diagnostic -DWA_ANT_TIME build): is a walk launch as long as (its longest walk x the
 average step), or are the long walks slower per step / is there a fixed part?   python tools/ant_time.py [generations]"""
 import os, subprocess, sys
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANT = os.path.join(ROOT, "build", "variants", "ant_time.so")

@@ -5,6 +5,7 @@ generation range (diagnostic) -- where do the 150 generations of a batch spend t
     python tools/c5_walk_profile.py [grid] [points] [slots] [generations] [batch]
 """
 import os, sys
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

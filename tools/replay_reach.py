@@ -2,6 +2,7 @@
 """How far do ants follow the best path before their first deviation, generation by generation?  Diagnostic
 (-DWA_STAMPS build): tells how much of the pre-convergence walk a replay of ONE path can cover."""
 import os, subprocess, sys
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANT = "/tmp/libweldacs_stamps.so"

@@ -7,6 +7,7 @@ per-generation trace bit for bit.  Prints the walk time summed over the generati
 """
 import json
 import os
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 import subprocess
 import sys
 

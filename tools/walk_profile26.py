@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-generation walk time of the 26-neighbour variant (diagnostic).   python tools/walk_profile26.py [generations]"""
 import os, sys
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -7,6 +7,7 @@ generations is  launch time / max steps of any ant  = time of one general (non-r
     python tools/walk_steps.py [generations] [grid] [ants]      (WA_REPLAY=0 to see the general loop only)
 """
 import os
+os.environ.setdefault("WA_STRAGGLER_DRAIN", "0")   # these generation-by-generation measurements assume every ant finishes inside its own launch (round 3 semantics)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
