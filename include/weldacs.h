@@ -222,10 +222,11 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
  * nodes, every 16 once shorter ants have arrived) it leaves the walk launch -- which lasts as long as its longest ant -- and a resume
  * block of the NEXT generation's walk launch finishes the same walk on the previous generation's field (intact until the next sweep),
  * adding its arrival and its steps to its own generation's trace entry.  Lists and pools are per slot: every search of a batch hands
- * its own stragglers over.  The last generation of a wa_acs_run call hands over too; its stragglers are finished by the next call's
- * first walk launch or -- when results are read first (wa_acs_sync, wa_acs_result, wa_acs_trace, wa_acs_read_ants ...) -- by a launch of
- * resume blocks only, which also puts the finished walks back into agents[] (WA_STRAGGLER_DRAIN=0: the last generation of a call
- * hands nothing over, as in round 3).  agents[] and the trace are complete whenever they are read.  Results are bit-identical with
+ * its own stragglers over.  The last generation of a wa_acs_run call hands over too once calls have been seen to follow each other
+ * without a read in between (chunked runs, generation-by-generation loops; behind a lone call it would only add a launch to what the
+ * caller waits for); its stragglers are finished by the next call's first walk launch or -- when results are read first
+ * (wa_acs_sync, wa_acs_result, wa_acs_trace, wa_acs_read_ants ...) -- by a launch of resume blocks only, which also puts the finished
+ * walks back into agents[] (WA_STRAGGLER_DRAIN=0: the last generation of a call never hands over, as in round 3).  agents[] and the trace are complete whenever they are read.  Results are bit-identical with
  * the mechanism on or off (WA_STRAGGLERS=0, read at wa_acs_create; wa_acs_set_stragglers(s, 0) at run time). */
 int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
 /* the same two counts per slot (ants handed over / stragglers finished by a resume block; equal whenever they are read) */

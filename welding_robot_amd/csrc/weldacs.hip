@@ -99,6 +99,10 @@ struct wa_acs {
     int32_t last_groups = 1;             // groups the last wa_acs_run call used (wa_acs_pipeline_info)
     bool drain_ok = true;                // WA_STRAGGLER_DRAIN: the last generation of a call may hand over too; whoever reads results first drains
     bool pending_resume = false;         // ... its stragglers sit in their pool: the next walk launch (or a drain launch) finishes them
+    // The last generation of a call only hands over when the caller has shown that calls follow each other without a read in between
+    // (chunked runs, generation-by-generation loops): behind a lone call the drain launch would only add to what the caller waits for
+    // (measured on bench.py --steps 20: -1 %).  ran_before / read_since_run track that pattern.
+    bool ran_before = false, read_since_run = false, chained = false;
 };
 
 static int fail(wa_ctx *c, int code, const char *fmt, const char *a = "")

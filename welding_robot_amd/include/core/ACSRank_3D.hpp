@@ -287,9 +287,14 @@ public:
         };
         // slots of shard 0 (the others are sized on their own device when their context exists); the primary's solver is rebuilt
         // if its size changed
+        if (rng_mode != WA_RNG_REF && concurrent_pairs <= 0 && solver) {
+            // sized by rule from the device's FREE memory: the one-slot solver initFromGridMap built must not count against it
+            wa_acs_destroy(solver); solver = NULL; slots = 0;
+        }
         shard_slots[0] = rng_mode == WA_RNG_REF ? 1 : slots_for(weldacs_dropin::context(), predict_path_len, (int)shard_pairs[0].size(), shard_pairs[0], pairs);
-        if (rng_mode != WA_RNG_REF && shard_slots[0] != slots) {
-            wa_acs_destroy(solver); solver = NULL;
+        if (rng_mode != WA_RNG_REF && (!solver || shard_slots[0] != slots)) {
+            if (solver) wa_acs_destroy(solver);
+            solver = NULL;
             slots_override = shard_slots[0];
             int rc = make_solver(weldacs_dropin::context(), device_grid(), predict_path_len, &solver);
             slots_override = 0;
