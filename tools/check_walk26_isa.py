@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check of what the 26-neighbour fast loop (k_walk_dev26, acs_kernels.hpp) relies on but the compiler does not promise
+"""Build-time check of what the 26-neighbour fast loop (k_walk_dev26, csrc/acs_nb26.hpp) relies on but the compiler does not promise
 (ADVICE r03): its next-step record loads are ISSUED by one inline statement and WAITED for by a later one (`s_waitcnt vmcnt(4)`), and its
 touch loads land in v250..v253, which only the statement's clobber list names.  Checked on the assembled kernel:
 

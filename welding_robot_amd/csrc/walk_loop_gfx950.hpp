@@ -1,5 +1,5 @@
 // walk_loop_gfx950.hpp -- the general step of the ant walk (ACS_Rank::selectNext, ACSRank_3D.hpp:134-193) as a
-// hand-scheduled gfx950 assembly loop.  Included by acs_kernels.hpp (needs WaRun, WaWalkState, wa_delta, wa_ctr_draw).
+// hand-scheduled gfx950 assembly loop.  Included by acs_walk.hpp (needs WaRun, WaWalkState, wa_delta, wa_ctr_draw).
 // Cost model it is scheduled for: tools/ubench/issue_rates.hip (profiles/r02/issue_rates.txt).
 #pragma once
 
