@@ -119,6 +119,46 @@ def test_random_search_in_ref_mode_equals_the_oracle(ctx, seed, nb):
     dg.close()
 
 
+@pytest.mark.parametrize("knobs", [{"WA_HASH_LOG2": "6"}, {"WA_HASH_LOG2": "8"}, {"WA_WALK_ASM": "0"}, {"WA_HASH_LOG2": "7", "WA_WALK_ASM": "0"}, {}])
+def test_ref_mode_on_the_hand_scheduled_loop_down_its_exits(ctx, knobs, monkeypatch):
+    """REF mode runs the hand-scheduled loop with the libc stream generated 64 draws at a time (round 4).  Medium corner-to-corner searches
+    (walks of several 64-step blocks: hand-backs at block boundaries, dead ends handed to the generic loop undecided) with tabu tables so small
+    that every walk outgrows the fast loop and finishes in the spilled one, with the compiler-scheduled loop instead, and as built: all
+    equal to the oracle's REF run down to the libc stream position."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for seed in (11, 12, 13):
+        rs = np.random.RandomState(seed)
+        nx, ny, nz = (int(rs.randint(24, 44)) for _ in range(3))
+        og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.05, 0.15, 0.25])), seed=seed)
+        og.free[0] = og.free[-1] = 1
+        n = nx * ny * nz
+        ants, iters, predict = int(rs.randint(8, 40)), 6, float(nx + ny + nz)
+        dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+        s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=ants)
+        s.srand(1000 + seed)
+        p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=ants, rng_mode=api.RNG_REF)
+        s.init_pheromone(1.0)
+        s.solve(p, 0, n - 1)
+        a = O.Acs(og)
+        rng = O.srand(1000 + seed)
+        tr = a.solve(0, n - 1, iters, predict, fixed_colony=ants, mode=O.REF, rng=rng)
+        t = s.trace()
+        assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(t["finite"], tr["finite"]), (knobs, seed)
+        assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(bits(t["iterbestL"]), bits(tr["iterbestL"]))
+        L, lens = s.ants()
+        olens, oL = a.last_ants()
+        assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL))
+        for i, op in enumerate(a.last_paths()):
+            assert np.array_equal(s.ant_path(i), op), (knobs, seed, i)
+        assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+        st = s.rand_state()
+        assert [int(v) for v in st[:31]] == [int(v) for v in rng.r[:31]] and (int(st[34]), int(st[35])) == (int(rng.f), int(rng.b))
+        assert int(tr["steps"].max()) > 64 * ants // 4          # the walks really span several blocks
+        s.close()
+        dg.close()
+
+
 # ------------------------------------------------------------------ voxelisation (a3 / N1)
 @pytest.mark.parametrize("seed", range(400, 424))
 def test_random_mesh_voxelisation_equals_the_oracle(ctx, seed):
