@@ -92,8 +92,7 @@ struct wa_acs {
     // sweep runs under another group's latency-bound walk.  Forked from / joined into the context's stream inside every wa_acs_run call.
     int32_t pipe_groups_env = 0;         // WA_PIPE_GROUPS, read at creation (0: by rule)
     std::vector<hipStream_t> gstream;
-    std::vector<hipEvent_t> gjoin, gchain;
-    bool pipe_chain = false;             // WA_PIPE_CHAIN: the groups' sweeps run one after another (event chain across the streams)
+    std::vector<hipEvent_t> gjoin;
     int32_t sweep_nt_env = -1;           // WA_SWEEP_NT: cache policy of the sweep (-1: by rule)
     hipEvent_t gfork = nullptr;
     int32_t last_groups = 1;             // groups the last wa_acs_run call used (wa_acs_pipeline_info)
