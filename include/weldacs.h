@@ -188,6 +188,8 @@ int wa_acs_result(wa_acs *s, int32_t slot, float *cost, int64_t *len, int32_t *p
  * +inf), and -- if path_ids is not NULL -- slot q's path ids at path_ids[q*path_stride ...]; WA_ERR_CAPACITY when a
  * path is longer than path_stride (lens is filled in either way: call again with a larger buffer). */
 int wa_acs_result_batch(wa_acs *s, int32_t n_slots, float *costs, int64_t *lens, int32_t *path_ids, int64_t path_stride);
+/* ... and the edge choices (Agent::nodeIndex(), as wa_acs_result's `choices`): slot q's lens[q] - 1 edge indices at choices[q*path_stride ...] */
+int wa_acs_result_batch_choices(wa_acs *s, int32_t n_slots, float *costs, int64_t *lens, int32_t *path_ids, int8_t *choices, int64_t path_stride);
 /* per-generation history the reference computes and discards (:295-296).  Arrays of
  * generations_done entries; any pointer may be NULL. */
 int wa_acs_trace(wa_acs *s, int32_t slot, int32_t *generations_done, float *best_L, float *iter_best_L,

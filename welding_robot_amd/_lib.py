@@ -68,6 +68,7 @@ SYMBOLS = {
     "wa_acs_solve": (C.c_int, [_V, C.POINTER(AcsParams), _I, _P, _P, _P]),
     "wa_acs_result": (C.c_int, [_V, _I, _P, _P, _P, _P, _I64]),
     "wa_acs_result_batch": (C.c_int, [_V, _I, _P, _P, _P, _I64]),
+    "wa_acs_result_batch_choices": (C.c_int, [_V, _I, _P, _P, _P, _P, _I64]),
     "wa_acs_trace": (C.c_int, [_V, _I, _P, _P, _P, _P, _P, _P]),
     "wa_acs_export_trace": (C.c_int, [_V, _V, _I, _I]),
     "wa_acs_read_pheromone": (C.c_int, [_V, _I, _P]),
