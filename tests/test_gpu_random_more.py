@@ -159,6 +159,53 @@ def test_ref_mode_on_the_hand_scheduled_loop_down_its_exits(ctx, knobs, monkeypa
         dg.close()
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_ref_mode_speculates_converged_generations_and_nothing_changes(ctx, seed, monkeypatch):
+    """Once a REF colony has converged every ant re-walks the best path, so the draws each ant is dealt are known in advance: the stream of
+    the generation is generated ahead, the ants check in parallel that they follow the whole path and the sequential walk starts at the
+    first one that does not (include/weldacs.h, wa_acs_debug_counters).  Small open grids converge within a few generations: with the
+    speculation on and off the trace, every ant's path, the field and the libc stream position are equal -- and equal to the oracle's REF run
+    -- and the speculation confirmed ants."""
+    rs = np.random.RandomState(seed)
+    nx, ny, nz = (int(rs.randint(10, 22)) for _ in range(3))
+    og = box_grid(nx, ny, nz, occ_prob=float(rs.choice([0.0, 0.05])), seed=seed)
+    og.free[0] = og.free[-1] = 1
+    n = nx * ny * nz
+    ants, iters, predict = int(rs.randint(12, 48)), 60, float(nx + ny + nz)
+    out = np.zeros(16, np.uint64)
+    res = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("WA_REF_SPEC", spec)
+        dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+        s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=ants)
+        s.srand(77 + seed)
+        p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=ants, rng_mode=api.RNG_REF)
+        s.init_pheromone(1.0)
+        ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 1))
+        s.solve(p, 0, n - 1)
+        ctx.check(ctx.lib.wa_acs_debug_counters(s.h, out.ctypes.data, 0))
+        confirmed = int(out[6])
+        assert (confirmed > ants) if spec == "1" else (confirmed == 0)       # it engaged (whole generations' worth of ants), or it is off
+        t = s.trace()
+        L, lens = s.ants()
+        st = s.rand_state()
+        res[spec] = (t["steps"].copy(), t["finite"].copy(), bits(t["bestL"]).copy(), bits(L).copy(), lens.copy(), [s.ant_path(i).copy() for i in range(ants)],
+                     bits(s.pheromone()).copy(), [int(v) for v in st[:31]] + [int(st[34]), int(st[35])])
+        s.close()
+        dg.close()
+    a = O.Acs(og)
+    rng = O.srand(77 + seed)
+    tr = a.solve(0, n - 1, iters, predict, fixed_colony=ants, mode=O.REF, rng=rng)
+    olens, oL = a.last_ants()
+    want = (tr["steps"], tr["finite"], bits(tr["bestL"]), bits(oL), olens, a.last_paths(), bits(a.pheromone()), [int(v) for v in rng.r[:31]] + [int(rng.f), int(rng.b)])
+    for spec in res:
+        for k, (g_, w) in enumerate(zip(res[spec], want)):
+            if k == 5:
+                assert all(np.array_equal(x, y) for x, y in zip(g_, w)), (spec, "ant paths")
+            else:
+                assert np.array_equal(g_, w), (spec, k)
+
+
 # ------------------------------------------------------------------ voxelisation (a3 / N1)
 @pytest.mark.parametrize("seed", range(400, 424))
 def test_random_mesh_voxelisation_equals_the_oracle(ctx, seed):

@@ -50,6 +50,11 @@ struct WaAcsDev {
     int32_t *pool_n;               // [slot][2]   stragglers of generation g in pool [g & 1]
     int32_t *pool_rec;             // [slot][2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
     int32_t *pool_path;            // [slot][2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
+    // REF mode, converged colonies (k_ref_draws / k_walk_ref_spec / k_walk_ref): the libc stream generated ahead for a whole generation under
+    // the assumption that every ant follows the best path, so that the ants can check that assumption IN PARALLEL
+    int32_t *ref_draws;            // [max_colony * WA_REF_SPEC_LEN] the next colony * (best_len - 1) outputs of the stream, in order
+    int32_t *ref_state;            // [blocks + 1][32] rotated state (lane j = r[(f + j) % 31]) in front of stream output 64 * block
+    int32_t *ref_ok;               // [max_colony + 2] per ant: followed the whole best path with the draws it was dealt; [max_colony] = speculation active, [max_colony + 1] = steps per ant
     unsigned long long *strag_cnt; // [slot][2]  ants handed over / stragglers finished by a resume block, per slot (wa_acs_straggler_counters)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
@@ -58,6 +63,7 @@ struct WaAcsDev {
     int32_t vbits_rows;            // bitmap rows per slot: max_colony (+ WA_RESUME_MAX rows of the resume blocks when the solver has straggler pools)
 };
 
+#define WA_REF_SPEC_LEN 4096       // longest best path (in steps) for which a REF generation is speculated
 #define WA_RESUME_MAX 256
 #define WA_POOL_REC 4
 

@@ -407,7 +407,9 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
 // edge the ant rebuilds its tabu hash from the prefix and continues in the general loop, which
 // recomputes that step in full.  After convergence nearly every step of every ant is a replay step.
 // Returns 1 dead end at node i, 2 arrived, 3 deviates at node i (i in `node`).
-__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node)
+// draws != nullptr (REF mode, k_walk_ref_spec): the draw of step i is draws[i] -- the libc stream's output the ant would be dealt if every
+// ant in front of it followed the whole best path -- instead of the counter hash
+__device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32_t rlen, uint64_t antkey, int32_t &node, const int32_t *__restrict__ draws = nullptr)
 {
     // Replay steps do not depend on each other while the ant stays on the path, so 64 consecutive nodes
     // are checked at once, ONE LANE PER NODE: the lane reads its node's 32-byte row (two coalesced 16-B
@@ -430,7 +432,7 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32
             a = T4[2 * nv];
             b = T4[2 * nv + 1];
         }
-        float rnd = (float)wa_ctr_draw(antkey, (uint32_t)nodev) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
+        float rnd = (float)(draws ? (valid ? draws[nodev] : 0) : (int32_t)wa_ctr_draw(antkey, (uint32_t)nodev)) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
         rnd *= cb.z;                                                               // :170, total
         const int nk = __float_as_int(cb.w);
         // thr = admissible ? prob_sum : -inf   (:178)
@@ -1032,9 +1034,66 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
 #endif
 }
 
+// ---- REF mode once the colony has converged: every ant re-walks the best path, L = best_len - 1 steps and as many draws each, so ant a
+// is dealt stream outputs [a * L, (a + 1) * L) -- IF every ant in front of it does the same.  Three launches per generation:
+//   k_ref_draws      one wavefront generates colony * L outputs of the libc stream ahead (64 per pass, wa_glibc_block) and keeps the
+//                    rotated state in front of every 64th output;
+//   k_walk_ref_spec  one wavefront per ant checks with the replay table whether the ant, dealt those draws, follows the whole best path
+//                    (the same test the DEV-mode replay makes, one lane per node) and, if so, delivers its result;
+//   k_walk_ref       takes the stream to the first ant A that did NOT (all ants in front of it are confirmed, so ITS offset is right),
+//                    and walks ants A .. colony-1 one after another as ever.  A = colony: nothing left to walk.
+// Every ant's draws are the reference's; a generation that still explores costs one wasted pass of the generator (~0.7 ms).
+__global__ __launch_bounds__(64) void k_ref_draws(WaAcsDev D, WaRun R, int32_t gen)
+{
+    const int lane = threadIdx.x;
+    const WaSlotCtl *c = &D.ctl[0];
+    const int32_t colony = c->colony[gen & 1];
+    const int32_t L = (D.rtab && c->bestL != INFINITY) ? c->best_len - 1 : 0;
+    // only once the best path has been stable for a few generations: while the colony explores the first ant already leaves it
+    const bool on = R.alpha == 1 && L >= 1 && L <= WA_REF_SPEC_LEN && colony >= 2 && colony <= D.max_colony && gen - c->tabu_gen >= 3;
+    if (lane == 0) { D.ref_ok[D.max_colony] = on ? 1 : 0; D.ref_ok[D.max_colony + 1] = L; }
+    if (!on) return;
+    const int32_t f0 = D.rng->f;
+    int32_t rot = wa_glibc_rotate(lane < 31 ? D.rng->r[lane] : 0, f0);
+    const int64_t total = (int64_t)colony * L;
+    for (int64_t t = 0; t < total; t += 64) {
+        if (lane < 32) D.ref_state[(t >> 6) * 32 + lane] = rot;
+        int32_t raw;
+        wa_glibc_block_raw<64, 0>(rot, raw);
+        if (t + lane < total) D.ref_draws[t + lane] = raw;
+    }
+    if (lane < 32) D.ref_state[((total + 63) >> 6) * 32 + lane] = rot;
+}
+
+__global__ __launch_bounds__(64) void k_walk_ref_spec(WaAcsDev D, WaRun R, int32_t gen)
+{
+    const int lane = threadIdx.x;
+    const int32_t ant = blockIdx.x;
+    if (!D.ref_ok[D.max_colony]) return;
+    const WaSlotCtl *c = &D.ctl[0];
+    const int32_t colony = c->colony[gen & 1];
+    if (ant >= colony) return;
+    const int32_t L = D.ref_ok[D.max_colony + 1], rlen = L + 1;
+    int32_t node = 0;
+    const int what = wa_walk_replay(D.rtab, rlen, 0, node, D.ref_draws + (int64_t)ant * L);
+    if (what != 2) {
+        if (lane == 0) D.ref_ok[ant] = 0;
+        return;
+    }
+    // the ant re-walked the best path: its agents[] entry is that path (:76-78), arriving accumulates exactly the steps that produced best.L
+    int32_t *path = D.paths + (int64_t)ant * D.path_cap;
+    for (int32_t q = lane; q < rlen; q += 64) path[q] = D.bestpath[q];
+    if (lane == 0) {
+        D.antL[ant] = c->bestL;
+        D.antLen[ant] = rlen;
+        D.ref_ok[ant] = 1;
+    }
+}
+
 // REF: grid = (1, 1): the ants of the single in-flight problem walk one after another and draw
 // from the shared glibc stream in exactly the reference's order (:252-261)
 // walk_flags bit 0 (and alpha == 1): the hand-scheduled loop with draws from the libc stream, 64 at a time (walk_loop_gfx950.hpp, REFDRAW)
+// walk_flags bit 1: k_ref_draws / k_walk_ref_spec ran in front of this launch (see above)
 __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -1047,11 +1106,33 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
     int32_t r = threadIdx.x < 31 ? D.rng->r[threadIdx.x] : 0;   // lane j holds word j of the state (see wa_glibc_next_lanes)
     int32_t f = D.rng->f, b = D.rng->b;
     const int32_t start = c->start, end = c->end, heur_slot = c->heur_slot;
+    int32_t first = 0;
+    if ((walk_flags & 2) && D.ref_ok[D.max_colony]) {
+        // the first ant that did not follow the whole best path with the draws it was dealt; everything in front of it stands
+        first = colony;
+        for (int32_t a0 = 0; a0 < colony; a0 += 64) {
+            const int32_t a = a0 + (int32_t)threadIdx.x;
+            const unsigned long long bad = __ballot(a < colony && D.ref_ok[a] == 0);
+            if (bad) { first = a0 + __ffsll((long long)bad) - 1; break; }
+        }
+        // the stream in front of that ant's first draw = output index first * L: the kept state in front of the 64-block it lies in,
+        // then the remaining outputs one by one
+        const int64_t t = (int64_t)first * D.ref_ok[D.max_colony + 1];
+        const int32_t rot = threadIdx.x < 32 ? D.ref_state[(t >> 6) * 32 + threadIdx.x] : 0;
+        f = (int32_t)((f + ((t >> 6) << 6)) % 31);
+        r = wa_glibc_unrotate(rot, f);
+        b = f + 28;
+        b = b >= 31 ? b - 31 : b;
+        for (int32_t q = 0; q < (int32_t)(t & 63); q++) (void)wa_glibc_next_lanes(r, f, b);
+#if !defined(WA_STAMPS) && !defined(WA_ANT_TIME)
+        if (threadIdx.x == 0 && D.dbg) atomicAdd(&D.dbg[6], (unsigned long long)first);   // ants confirmed by the speculation (wa_acs_debug_counters)
+#endif
+    }
     if (R.alpha == 1 && (walk_flags & 1)) {
-        for (int32_t ant = 0; ant < colony; ant++)
+        for (int32_t ant = first; ant < colony; ant++)
             wa_walk_one<0, true, false, true, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 1, 0u, heur_slot);
     } else {
-        for (int32_t ant = 0; ant < colony; ant++)
+        for (int32_t ant = first; ant < colony; ant++)
             wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);
     }
     if (threadIdx.x < 31) D.rng->r[threadIdx.x] = r;

@@ -689,6 +689,19 @@ struct WaGlibcUnroll<COUNT, LANE0, COUNT> {
         }
     }
 };
+// (the outputs as integers, lane LANE0 + n = output n)
+template <int COUNT, int LANE0>
+__device__ __forceinline__ void wa_glibc_block_raw(int32_t &rot, int32_t &raw_out)
+{
+    uint32_t r[31];
+#pragma unroll
+    for (int j = 0; j < 31; j++) r[j] = (uint32_t)__builtin_amdgcn_readlane(rot, j);
+    int32_t raw = 0;
+    WaGlibcUnroll<COUNT, LANE0>::out(r, raw);
+    WaGlibcUnroll<COUNT, LANE0>::back(r, rot);
+    static_assert(COUNT >= 31, "the write-back recursion covers lanes 0..30 only when COUNT >= 31");
+    raw_out = raw;
+}
 template <int COUNT, int LANE0>
 __device__ __forceinline__ void wa_glibc_block(int32_t &rot, float &ub)
 {

@@ -96,6 +96,7 @@ struct wa_acs {
     int32_t sweep_nt_env = -1;           // WA_SWEEP_NT: cache policy of the sweep (-1: by rule)
     hipEvent_t gfork = nullptr;
     int32_t last_groups = 1;             // groups the last wa_acs_run call used (wa_acs_pipeline_info)
+    bool ref_spec = true;                // WA_REF_SPEC: REF mode speculates converged generations (k_ref_draws / k_walk_ref_spec)
     bool drain_ok = true;                // WA_STRAGGLER_DRAIN: the last generation of a call may hand over too; whoever reads results first drains
     bool pending_resume = false;         // ... its stragglers sit in their pool: the next walk launch (or a drain launch) finishes them
     // The last generation of a call only hands over when the caller has shown that calls follow each other without a read in between
