@@ -37,6 +37,8 @@ python3 tools/pipeline_curve.py --P 1,2,4,8,16,32 --G 1,2,3,4 --kinds dense,lazy
 # 5. the smaller measurements
 python3 tools/sweep_nt.py > $O/sweep_nt.txt 2>&1
 python3 tools/ref_time.py 500 > $O/ref_time.txt 2>&1
+WA_REF_SPEC=0 python3 tools/ref_time.py 500 2>&1 | head -1 >> $O/ref_time.txt
+python3 tools/ref_profile.py 500 > $O/ref_profile.txt 2>&1
 python3 tools/scalar_calls.py $O/scalar_calls.txt > /dev/null 2>&1
 python3 tests/tools/nb26_time.py 300 > $O/nb26_time.txt 2>&1
 python3 examples/plan_batch.py --grid 256 --points 64 --lazy > $O/plan_batch_c5.jsonl 2>&1
