@@ -217,6 +217,26 @@ def full_run_extra(solver, params, ids, wl, n, gens=500):
             "in_loop_frac": 48.0 * n ** 3 / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fused_ms > 0 else None}
 
 
+def ref_mode_extra(solver, ids, n, ants, gens=200):
+    """WA_RNG_REF on the same grid: the reference's own libc rand() stream and std::sort tie order, bit for bit (what the REF goldens pin
+    against the reference itself).  Ants walk one after another while the colony explores; converged generations are speculated in
+    parallel.  Outside `value`; ~1.5 s."""
+    from welding_robot_amd import api
+    p = api.default_params(max_iteration=gens, predict=PREDICT * ants / ANTS, fixed_colony=ants, rng_mode=api.RNG_REF)
+    solver.srand(12345)
+    solver.init_pheromone(1.0)
+    solver.begin(p, ids[0], ids[1])
+    solver.ctx.sync()
+    t0 = time.perf_counter()
+    solver.run(gens)
+    solver.sync()
+    dt = time.perf_counter() - t0
+    cost, path, _ = solver.result()
+    tr = solver.trace()
+    return {"workload": "%d^3 / %d ants, %d generations in WA_RNG_REF mode (srand(12345))" % (n, ants, gens), "generations_per_s": gens / dt, "ms_total": dt * 1e3,
+            "ns_per_ant_step": dt * 1e9 / max(int(tr["steps"].sum()), 1), "best_cost": float(cost), "path_nodes": int(len(path))}
+
+
 def live_traffic(n, ants, timeout_s=90):
     """HBM bytes per launch of the in-loop sweep launch, measured in THIS run: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as the guide's HBM section prescribes; 30 generations each),
@@ -615,6 +635,7 @@ def main():
             out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
             out["full_run"] = full_run_extra(solver, params, ids, wl, n)
+            out["ref_mode"] = ref_mode_extra(solver, ids, n, args.ants)
             out["multi_start"] = multi_start_extra(ctx, grid, params, ids, n, args.ants)
             out["multi_start_curve"] = multi_start_curve_extra(ctx, grid, ids, n, args.ants)
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)

@@ -52,6 +52,8 @@ def test_bench_json_contract():
     assert all(r["identical_to_one_stream"] for r in mc if r["groups"] > 1) and any(r["groups"] == 2 for r in mc)
     ks = d["kernel_ms_sampled"]
     assert ks["generations"] == [0, 10, 20, 30, 40, 50] and ks["walk"] > 0
+    rm = d["ref_mode"]    # the reference's own rand() stream on the same grid: converged by generation 200, far faster than a walk per ant
+    assert rm["best_cost"] == 378.0 and rm["generations_per_s"] > 40
     fr, c5 = d["full_run"], d["c5_full"]
     assert fr["generations"] == 500 and fr["best_cost"] == 378.0 and fr["generations_per_s"] > d["value"]
     assert c5["all_reached"] is True and c5["slots_by_rule"] * c5["batches"] >= 2016 and c5["t_pairs_s"] < 10
