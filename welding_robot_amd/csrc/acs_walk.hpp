@@ -1042,7 +1042,13 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
 //                    (the same test the DEV-mode replay makes, one lane per node) and, if so, delivers its result;
 //   k_walk_ref       takes the stream to the first ant A that did NOT (all ants in front of it are confirmed, so ITS offset is right),
 //                    and walks ants A .. colony-1 one after another as ever.  A = colony: nothing left to walk.
-// Every ant's draws are the reference's; a generation that still explores costs one wasted pass of the generator (~0.7 ms).
+// Every ant's draws are the reference's.
+// The generator in two steps, because one wavefront producing 64 outputs per pass needs 1 ms for the ~97 000 outputs of a generation:
+//   k_ref_draws        one wavefront takes the state from superblock to superblock (WA_REF_SUPER = 1024 outputs each) by a matrix-vector
+//                      product over Z/2^32 -- the recurrence is linear: state(n + 1024) = J * state(n), J = companion matrix ^ 1024, computed
+//                      once on the host -- lane i = row i, 31 broadcast multiply-adds per superblock (~95 superblocks: ~20 us);
+//   k_ref_draws_fill   one wavefront per superblock generates its 1024 outputs (16 passes of wa_glibc_block) and keeps the rotated state in
+//                      front of every 64th.
 __global__ __launch_bounds__(64) void k_ref_draws(WaAcsDev D, WaRun R, int32_t gen)
 {
     const int lane = threadIdx.x;
@@ -1053,16 +1059,36 @@ __global__ __launch_bounds__(64) void k_ref_draws(WaAcsDev D, WaRun R, int32_t g
     const bool on = R.alpha == 1 && L >= 1 && L <= WA_REF_SPEC_LEN && colony >= 2 && colony <= D.max_colony && gen - c->tabu_gen >= 3;
     if (lane == 0) { D.ref_ok[D.max_colony] = on ? 1 : 0; D.ref_ok[D.max_colony + 1] = L; }
     if (!on) return;
-    const int32_t f0 = D.rng->f;
-    int32_t rot = wa_glibc_rotate(lane < 31 ? D.rng->r[lane] : 0, f0);
+    uint32_t row[31];                                    // row `lane` of the jump matrix
+#pragma unroll
+    for (int j = 0; j < 31; j++) row[j] = lane < 31 ? D.ref_jump[lane * 31 + j] : 0u;
+    int32_t rot = wa_glibc_rotate(lane < 31 ? D.rng->r[lane] : 0, D.rng->f);
     const int64_t total = (int64_t)colony * L;
-    for (int64_t t = 0; t < total; t += 64) {
-        if (lane < 32) D.ref_state[(t >> 6) * 32 + lane] = rot;
+    const int64_t supers = (total + WA_REF_SUPER - 1) / WA_REF_SUPER;
+    for (int64_t sb = 0; sb <= supers; sb++) {           // (one more than needed: the state behind the last output of a full last superblock)
+        if (lane < 32) D.ref_state[sb * (WA_REF_SUPER / 64) * 32 + lane] = rot;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 31; j++) acc += row[j] * (uint32_t)__builtin_amdgcn_readlane(rot, j);
+        rot = (int32_t)acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ref_draws_fill(WaAcsDev D, WaRun R, int32_t gen)
+{
+    const int lane = threadIdx.x;
+    if (!D.ref_ok[D.max_colony]) return;
+    const int64_t total = (int64_t)D.ctl[0].colony[gen & 1] * D.ref_ok[D.max_colony + 1];
+    const int64_t t0 = (int64_t)blockIdx.x * WA_REF_SUPER;
+    if (t0 >= total) return;
+    int32_t rot = lane < 32 ? D.ref_state[(t0 >> 6) * 32 + lane] : 0;
+    for (int64_t t = t0; t < t0 + WA_REF_SUPER; t += 64) {
+        if (t != t0 && lane < 32) D.ref_state[(t >> 6) * 32 + lane] = rot;   // (also at t == total: the state behind the last output)
+        if (t >= total) break;
         int32_t raw;
         wa_glibc_block_raw<64, 0>(rot, raw);
         if (t + lane < total) D.ref_draws[t + lane] = raw;
     }
-    if (lane < 32) D.ref_state[((total + 63) >> 6) * 32 + lane] = rot;
 }
 
 __global__ __launch_bounds__(64) void k_walk_ref_spec(WaAcsDev D, WaRun R, int32_t gen)
