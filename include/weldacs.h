@@ -235,7 +235,7 @@ int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_
  * to walk one after another because an ant's first draw is the previous ants' total step count -- but when every ant re-walks the best path
  * that count is known.  The stream of the whole generation is generated ahead, every ant checks IN PARALLEL (replay table) that it follows
  * the whole best path with the draws it would be dealt, and the sequential walk starts at the first ant that does not, with the stream taken
- * to exactly that ant's first draw.  Same draws, same results, same stream position as the reference (BASELINE config 3, 500 REF generations: 8.7 -> 1.65 s). */
+ * to exactly that ant's first draw.  Same draws, same results, same stream position as the reference (BASELINE config 3, 500 REF generations: 8.7 -> 1.25 s). */
 int wa_acs_debug_counters(wa_acs *s, uint64_t out16[16], int32_t reset);
 /* the same two counts per slot (ants handed over / stragglers finished by a resume block; equal whenever they are read) */
 int wa_acs_straggler_counters(wa_acs *s, int32_t slot, uint64_t *handed_over, uint64_t *resumed, int32_t reset);

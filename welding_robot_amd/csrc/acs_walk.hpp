@@ -432,7 +432,7 @@ __device__ __forceinline__ int wa_walk_replay(const float *__restrict__ T, int32
             a = T4[2 * nv];
             b = T4[2 * nv + 1];
         }
-        float rnd = (float)(draws ? (valid ? draws[nodev] : 0) : (int32_t)wa_ctr_draw(antkey, (uint32_t)nodev)) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
+        float rnd = (float)(draws ? (valid ? __hip_atomic_load(&draws[nodev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0) : (int32_t)wa_ctr_draw(antkey, (uint32_t)nodev)) / 2147483648.0f;  // (float)rand()/(float)RAND_MAX (:169)
         rnd *= cb.z;                                                               // :170, total
         const int nk = __float_as_int(cb.w);
         // thr = admissible ? prob_sum : -inf   (:178)
@@ -531,7 +531,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                                             int hash_log2, int32_t &rng_rs, int32_t &rng_f, int32_t &rng_b,
                                             int32_t *flags_out, int32_t rlen, float bestL, float clean, uint32_t evap_now, int32_t walk_flags,
                                             uint32_t best_ver, int32_t heur_slot, int32_t cut_n = 0x7fffffff, const int32_t *res_words = nullptr,
-                                            int32_t res_len = 0, int32_t gen = 0, int32_t bits_row = -1)
+                                            int32_t res_len = 0, int32_t gen = 0, int32_t bits_row = -1,
+                                            const int32_t *ref_draws = nullptr, const int32_t *ref_snap = nullptr, int32_t *replayed_out = nullptr)
 {
     // cut_n: straggler check (0x7fffffff = off).  res_words / res_len: this block RESUMES a straggler of the previous generation -- the
     // walk continues behind its res_len nodes (D.pher is then that generation's field, rlen 0, no rejoin watch) and only its statistics
@@ -553,7 +554,9 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         st.step = (uint32_t)(res_len - 1);
         for (int32_t q = 0; q < res_len - 1; q++) st.L += R.precision;   // :78, one add per step taken
         prefix_words = res_words;
-    } else if (MODE == 1 && rlen > 1) {
+    } else if ((MODE == 1 || ref_draws) && rlen > 1) {
+        // (REF mode, ref_draws: the next rlen - 1 outputs of the libc stream, dealt ahead WITHOUT committing them; ref_snap: the rotated
+        //  state in front of every 64th of them -- the stream is then taken to the draws the ant really consumed, see k_walk_ref)
         int32_t node = 0;
         // the first 512 words of the best path are requested BEFORE the replay decides how many of them the ant walks: their round trip
         // runs beside the table rows' (once converged every ant copies all of them)
@@ -563,7 +566,11 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             const int32_t q = u * 64 + lane;
             w0[u] = q < rlen ? bpath[q] : 0;
         }
-        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node);
+        const int what = wa_walk_replay(D.rtab + (int64_t)slot * D.path_cap * 8, rlen, antkey, node, ref_draws);
+        if (MODE == 0) {   // one draw per step taken; a dead end on the path (what == 1: candidates, none picked) consumed its draw too (:169 before :178)
+            wa_glibc_seek(ref_snap, what == 2 ? rlen - 1 : what == 1 ? node + 1 : node, rng_rs, rng_f, rng_b);
+            if (replayed_out) *replayed_out = node;
+        }
 #ifdef WA_STAMPS
         if (lane == 0 && D.dbg) {   // diagnostic: how far do ants follow the best path?  [10] += nodes replayed, [11] += ants,
             atomicAdd(&D.dbg[10], (unsigned long long)node);          // [12] += ants that arrived on the replay track
@@ -1155,8 +1162,34 @@ __global__ __launch_bounds__(64) void k_walk_ref(WaAcsDev D, WaRun R, int hash_l
 #endif
     }
     if (R.alpha == 1 && (walk_flags & 1)) {
-        for (int32_t ant = first; ant < colony; ant++)
-            wa_walk_one<0, true, false, true, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 1, 0u, heur_slot);
+        // The ants that are left walk one after another.  While the replay table is good (same condition as the speculation) each of them
+        // is first dealt the next L outputs of the stream WITHOUT committing them and follows the best path for as long as its own draws
+        // take the path's edges (wa_walk_replay, one lane per node); the stream is then taken to the draws it really consumed and the
+        // general loop goes on from where it left the path.  Given up for the rest of the generation when the ants leave the path early.
+        const bool prefix_ok = (walk_flags & 2) && D.ref_ok[D.max_colony];
+        const int32_t L = prefix_ok ? D.ref_ok[D.max_colony + 1] : 0;
+        int32_t tried = 0, followed = 0;
+        for (int32_t ant = first; ant < colony; ant++) {
+            const bool prefix = prefix_ok && !(tried >= 16 && followed < 48 * tried);
+            if (prefix) {
+                int32_t rot = wa_glibc_rotate(r, f);
+                for (int32_t t = 0; t < L; t += 64) {
+                    if (threadIdx.x < 32) D.ref_state[(t >> 6) * 32 + threadIdx.x] = rot;
+                    int32_t raw;
+                    wa_glibc_block_raw<64, 0>(rot, raw);
+                    if (t + (int32_t)threadIdx.x < L) D.ref_draws[t + threadIdx.x] = raw;
+                }
+                if (threadIdx.x < 32) D.ref_state[((L + 63) >> 6) * 32 + threadIdx.x] = rot;
+                __threadfence();   // the replay reads them back through L2
+                int32_t replayed = 0;
+                wa_walk_one<0, true, false, true, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, L + 1, c->bestL, 0.f, 0u, 1, 0u, heur_slot,
+                                                         0x7fffffff, nullptr, 0, 0, -1, D.ref_draws, D.ref_state, &replayed);
+                tried++;
+                followed += replayed;
+            } else {
+                wa_walk_one<0, true, false, true, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 1, 0u, heur_slot);
+            }
+        }
     } else {
         for (int32_t ant = first; ant < colony; ant++)
             wa_walk_one<0, false, false>(D, R, slot, ant, start, end, 0, lds, hash_log2, r, f, b, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u, 0, 0u, heur_slot);

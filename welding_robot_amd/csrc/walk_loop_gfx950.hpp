@@ -730,6 +730,19 @@ __device__ __forceinline__ int32_t wa_glibc_unrotate(int32_t rot, int32_t f)
     return lane < 31 ? __builtin_amdgcn_ds_bpermute(src * 4, rot) : 0;
 }
 
+// take the canonical state (lane j = r[j], indices f, b) `k` outputs on, given the rotated states kept in front of every 64th output counted
+// from where it stands (snap row i = 32 words in front of output 64 * i; read through L2: the caller may have written them a moment ago)
+__device__ __forceinline__ void wa_glibc_seek(const int32_t *snap, int32_t k, int32_t &rs, int32_t &f, int32_t &b)
+{
+    const int lane = threadIdx.x;
+    const int32_t rot = lane < 32 ? __hip_atomic_load(&snap[(k >> 6) * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    f = (f + (k & ~63)) % 31;
+    rs = wa_glibc_unrotate(rot, f);
+    b = f + 28;
+    b = b >= 31 ? b - 31 : b;
+    for (int32_t q = 0; q < (k & 63); q++) (void)wa_glibc_next_lanes(rs, f, b);
+}
+
 // VARIANT 0: dense field.  1 (LAZY): the field of a lazily evaporating solver (stamp per voxel, see WaAcsDev); `stamp` is the
 // slot's stamp array, clean_info the value of a never-deposited admissible edge, evap_now the evaporations applied so far.
 // 2: dense field + rejoin watch (3: lazy field + rejoin watch): `mark` / `ver` = best-path membership stamps, hold_off = steps before a rejoin is reported;
