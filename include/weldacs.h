@@ -146,8 +146,9 @@ void wa_acs_destroy(wa_acs *s);
 int wa_acs_memory_estimate(const wa_grid *grid, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood, int32_t lazy,
                            int64_t *bytes_per_slot, int64_t *bytes_per_heuristic_field, int64_t *bytes_fixed);
 /* A dense solver (6 or 26 neighbours) of at most 256 ants and at most 16 slots (WA_STRAGGLER_SLOTS) additionally holds, PER SLOT, the
- * arrival list and the straggler pools (see wa_acs_debug_counters): 2 x 256 paths of path_capacity words + 256 spill-bitmap rows
- * (0.6 GB per slot at 128^3 with the default path capacity).  *bytes = what a solver of this shape holds in total, 0 when it
+ * arrival list and what the straggler hand-over needs (see wa_acs_debug_counters): a second array of ants' paths (max_colony x
+ * path_capacity words: stragglers walk on in place while the next generation writes the other array) + 256 spill-bitmap rows
+ * (0.33 GB per slot at 128^3 with 256 ants and the default path capacity).  *bytes = what a solver of this shape holds in total, 0 when it
  * gets none (lazy, larger colonies, more slots, WA_STRAGGLERS=0). */
 int wa_acs_straggler_pool_bytes(const wa_grid *grid, int32_t n_slots, int32_t max_colony, int64_t path_capacity, int32_t neighbourhood,
                                 int32_t lazy, int64_t *bytes);

@@ -13,7 +13,7 @@ struct WaAcsDev {
     uint8_t *besttabu;             // [slot][path_cap] bit k: neighbour k of best[i] lies on the prefix best[0..i]
     int32_t *bestpath;             // [slot][path_cap]
     float *rtab;                   // [slot][path_cap][8] replay table of the best path (see k_replay_table); may be null
-    int32_t *paths;                // [slot][max_colony][path_cap]
+    int32_t *paths;                // [slot][max_colony][path_cap]  (solvers that hand stragglers over keep TWO such arrays and alternate by generation: see prev_paths)
     float *antL;                   // [slot][max_colony]
     int32_t *antLen;               // [slot][max_colony]
     int32_t *perm;                 // [slot][max_colony]   rank o-1 -> ant
@@ -49,7 +49,7 @@ struct WaAcsDev {
     uint32_t *arr_n;               // [slot]
     int32_t *pool_n;               // [slot][2]   stragglers of generation g in pool [g & 1]
     int32_t *pool_rec;             // [slot][2][WA_RESUME_MAX][WA_POOL_REC]  (ant, node count at the hand-over, 26 neighbours: bits of L so far)
-    int32_t *pool_path;            // [slot][2][WA_RESUME_MAX][path_cap]  the straggler's path so far (its own slot belongs to the next generation's ant)
+    int32_t *prev_paths;           // [slot][max_colony][path_cap]  the paths of the PREVIOUS generation's ants: a straggler's walk so far stays where it is (no copy) and its resume block walks on in place, while the running generation's ants write `paths`
     // REF mode, converged colonies (k_ref_draws / k_walk_ref_spec / k_walk_ref): the libc stream generated ahead for a whole generation under
     // the assumption that every ant follows the best path, so that the ants can check that assumption IN PARALLEL
     int32_t *ref_draws;            // [max_colony * WA_REF_SPEC_LEN] the next colony * (best_len - 1) outputs of the stream, in order
@@ -72,7 +72,7 @@ struct WaAcsDev {
 // the arrival list and the straggler pools of ONE slot (every search of a launch hands its own stragglers over)
 struct WaStrag {
     uint32_t *arr_len, *arr_n;
-    int32_t *pool_n, *pool_rec, *pool_path;
+    int32_t *pool_n, *pool_rec;
 };
 __device__ __forceinline__ WaStrag wa_strag_of(const WaAcsDev &D, int32_t slot)
 {
@@ -81,7 +81,6 @@ __device__ __forceinline__ WaStrag wa_strag_of(const WaAcsDev &D, int32_t slot)
     g.arr_n = D.arr_n + slot;
     g.pool_n = D.pool_n + (int64_t)slot * 2;
     g.pool_rec = D.pool_rec + (int64_t)slot * 2 * WA_RESUME_MAX * WA_POOL_REC;
-    g.pool_path = D.pool_path + (int64_t)slot * 2 * WA_RESUME_MAX * D.path_cap;
     return g;
 }
 

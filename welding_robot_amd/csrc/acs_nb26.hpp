@@ -207,14 +207,9 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
                     atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(lenf - res_len));
                 }
             }
-            if (drain) {   // drain launch (see k_walk_dev): the finished walk goes back to agents[]
-                int32_t *own = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
-                __threadfence();
-                for (int32_t q = lane; q < lenf; q += 64) own[q] = __hip_atomic_load(&res_words[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) {
-                    D.antL[(int64_t)slot * D.max_colony + ant] = Lf;
-                    D.antLen[(int64_t)slot * D.max_colony + ant] = lenf;
-                }
+            if (drain && lane == 0) {   // drain launch (see k_walk_dev): the finished walk's result goes to agents[]
+                D.antL[(int64_t)slot * D.max_colony + ant] = Lf;
+                D.antLen[(int64_t)slot * D.max_colony + ant] = lenf;
             }
             return;
         }
@@ -389,20 +384,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             if (lane == 0) r = atomicAdd(&sg.pool_n[gen & 1], 1);
             r = __builtin_amdgcn_readfirstlane(r);
             if (r < WA_RESUME_MAX) {
-                int32_t *pp = sg.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
-                for (int32_t q0 = 0; q0 < len; q0 += 512) {   // (through L2: the last block was stored by this very wavefront a moment ago)
-                    int32_t w[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int32_t q = q0 + u * 64 + lane;
-                        w[u] = q < len ? __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int32_t q = q0 + u * 64 + lane;
-                        if (q < len) pp[q] = w[u];
-                    }
-                }
+                // (the path so far stays where it is: see WaAcsDev::prev_paths)
                 if (lane == 0) {
                     int32_t *rec = sg.pool_rec + ((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC;
                     rec[0] = ant; rec[1] = len; rec[2] = __float_as_int(L);
@@ -519,7 +501,7 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         wa_walk_one26<1>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, 0, 0x7fffffff,
-                         sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, L0, gen - 1, D.max_colony + r, (walk_flags & 64) != 0);
+                         D.prev_paths + ((int64_t)slot * D.max_colony + a) * D.path_cap, n0, L0, gen - 1, D.max_colony + r, (walk_flags & 64) != 0);
         return;
     }
     if (walk_flags & 64) return;   // drain launch: resume blocks only

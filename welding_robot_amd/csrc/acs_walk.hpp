@@ -656,22 +656,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) atomicSub(&sg.pool_n[gen & 1], 1);
             return false;
         }
-        int32_t *pp = sg.pool_path + ((int64_t)(gen & 1) * WA_RESUME_MAX + r) * D.path_cap;
-        // (through L2: the last, incomplete block was stored by this very wavefront a moment ago)
-        // 512 words per round: eight independent loads per lane, then eight stores (one memory round trip per round, not per 64 words)
-        for (int32_t q0 = 0; q0 < st.len; q0 += 512) {
-            int32_t w[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int32_t q = q0 + u * 64 + lane;
-                w[u] = q < st.len ? __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int32_t q = q0 + u * 64 + lane;
-                if (q < st.len) pp[q] = w[u];
-            }
-        }
+        // (the path so far stays where it is: the next generation's ants write the OTHER paths array, the resume block walks on in this one)
         if (lane == 0) {
             sg.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC] = ant;
             sg.pool_rec[((gen & 1) * WA_RESUME_MAX + r) * WA_POOL_REC + 1] = st.len;
@@ -806,11 +791,8 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (st.L != INFINITY) atomicAdd(&D.trFinite[t], 1);
             atomicAdd(reinterpret_cast<unsigned long long *>(&D.trSteps[t]), (unsigned long long)(st.len - res_len));
         }
-        if (walk_flags & 64) {   // drain launch (no newer generation's ant owns the slot): the finished walk goes back to agents[]
-            int32_t *own = D.paths + ((int64_t)slot * D.max_colony + ant) * D.path_cap;
-            __threadfence();     // (the last words were stored by this wavefront; read them back through L2)
-            for (int32_t q = lane; q < st.len; q += 64) own[q] = __hip_atomic_load(&path[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0) {
+        if (walk_flags & 64) {   // drain launch (no newer generation's ant owns the agents[] entry): the finished walk's result goes there
+            if (lane == 0) {     // (its path is where it always was: the previous generation's paths array, which is what wa_acs_read_ant_path reads)
                 D.antL[(int64_t)slot * D.max_colony + ant] = st.L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
             }
@@ -993,7 +975,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         int32_t f0 = 0, b0 = 0, rs0 = 0;
         wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
-                                                 walk_flags & (1 | 64), 0u, c->heur_slot, 0x7fffffff, sg.pool_path + ((int64_t)pg * WA_RESUME_MAX + r) * D.path_cap, n0, gen - 1,
+                                                 walk_flags & (1 | 64), 0u, c->heur_slot, 0x7fffffff, D.prev_paths + ((int64_t)slot * D.max_colony + a) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
 #ifdef WA_STRAG_TIME
         if (threadIdx.x == 0 && gen < 128) atomicMax(&wa_strag_t[gen * 8 + 3], (unsigned long long)wall_clock64());

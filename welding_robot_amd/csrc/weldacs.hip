@@ -59,6 +59,8 @@ struct wa_acs {
     int32_t n_slots, max_colony, n_active, nb;
     int64_t path_cap;
     WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
+    int32_t *paths_base = nullptr;   // the ants' paths: one array, or two (paths_half elements apart) alternating by generation when stragglers are handed over
+    size_t paths_half = 0;
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     float *pher_alloc[2], *heur_alloc;   // the allocations behind pher_buf[] / D.heur (fields + guard bands)
     uint32_t *stamp_alloc;               // ... and D.stamp (lazy solvers)
