@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "core/ACSRank_3D.hpp"
 #include "core/read_STL.hpp"
 #include "core/ACS_GTSP.hpp"
@@ -18,6 +20,18 @@
 STLReader model;
 ACS_Rank SearchPath;
 ACS_GTSP GlobalRoute;
+
+// WA_DEMO_TIMES=1: wall time of each planning call on stderr (tools/dropin_c5.py)
+static double lap(const char *what)
+{
+    static const bool on = getenv("WA_DEMO_TIMES") && atoi(getenv("WA_DEMO_TIMES"));
+    static auto t_last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    const double dt = std::chrono::duration<double>(now - t_last).count();
+    t_last = now;
+    if (on && what) fprintf(stderr, "[demo] %-28s %.3f s\n", what, dt);
+    return dt;
+}
 
 int main(int argc, char **argv)
 {
@@ -36,14 +50,20 @@ int main(int argc, char **argv)
     SearchPath.setSeed(seed);
     GlobalRoute.setSeed(seed);
 
+    lap(NULL);
     if (!model.readFile(argv[1])) return 1;                                   // main.cpp:273
     const std::vector<Triangles<float>> meshes = model.TriangleList();         // :274
+    lap("readFile");
     SearchPath.creatGridMap(meshes, strtof(argv[2], NULL), atoi(argv[3]), ""); // :279
+    lap("creatGridMap");
     SearchPath.searchBestPathOfPoints(strtof(argv[5], NULL), argv[4], argv[6]);// :280
+    lap("searchBestPathOfPoints");
     if (SearchPath.lastStatus() != WA_OK) return 3;
     GlobalRoute.readFromGraphFile(argv[6]);                                    // :281
     GlobalRoute.computeSolution();                                             // :282
+    lap("graph file + computeSolution");
     GlobalRoute.read_all_segments(SearchPath.best_matrix);                     // :283
+    lap("read_all_segments");
 
     FILE *out = argc > 9 ? fopen(argv[9], "w") : stdout;
     int P = (int)SearchPath.route_points.size();
@@ -101,5 +121,6 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < s2.size() / 3; i++) fprintf(out, "%.9g %.9g %.9g\n", (double)s2[i * 3], (double)s2[i * 3 + 1], (double)s2[i * 3 + 2]);
     }
     if (out != stdout) fclose(out);
+    lap("smoothing + result file");
     return 0;
 }

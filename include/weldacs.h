@@ -51,6 +51,13 @@ int wa_device_count(void);
 /* free / total memory of the context's device in bytes (either pointer may be NULL): what the slot count of a solver for many
  * pair searches is sized by, and what a caller can poll after another process has just released the GPU */
 int wa_ctx_memory_info(wa_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
+/* A context keeps the device blocks (1 MiB and up) of the solvers destroyed on it and hands them to the next solver it creates: the
+ * reference never frees anything (SURVEY 8(b) ownership) and creates its search once per process; a host that runs
+ * searchBestPathOfPoints per job would otherwise pay the driver's wipe of the freed memory before every re-allocation (seconds for
+ * a C5-sized solver).  Kept bytes count as free in wa_ctx_memory_info and go back to the driver when the device runs out, on
+ * wa_ctx_trim and with the context.  WA_DEV_CACHE=0 in the environment switches the mechanism off. */
+int wa_ctx_cached_bytes(wa_ctx *ctx, int64_t *bytes);
+int wa_ctx_trim(wa_ctx *ctx);
 /* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling
  * thread's current HIP device, and restores the caller's current device before returning. */
 int wa_ctx_create(int device_ordinal, wa_ctx **out);

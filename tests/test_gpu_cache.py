@@ -1,0 +1,116 @@
+"""The context's block cache (wa_ctx_cached_bytes / wa_ctx_trim; include/weldacs.h): a solver's device blocks stay with the context when
+the solver is destroyed and the next solver gets them back -- with whatever the previous solver left in them.  A search must not see any
+of it: solvers built on reused blocks, and on blocks filled with 0xff bytes before they are handed out (WA_DEV_POISON=1), equal the
+oracle in every word -- trace, ants, best path, whole field -- in every mode (dense, lazy, 26 neighbours, REF stream)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from welding_robot_amd import api
+from test_gpu_edges import bits, box_grid
+from test_gpu_pipeline import assert_slot, oracle_run, slot_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    og = box_grid(40, 36, 44, occ_prob=0.1, seed=33)
+    n = 40 * 36 * 44
+    og.free[0] = og.free[-1] = og.free[n // 2 + 5] = 1
+    return og, n
+
+
+def run_once(ctx, og, n, kind, P, iters=10, ants=48, predict=120.0, seed=99):
+    nb = 26 if kind == "nb26" else 6
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, P, ants, neighbourhood=nb, lazy=kind == "lazy")
+    ends = [n - 1 if q % 2 else n // 2 + 5 for q in range(P)]
+    streams = [3 + q for q in range(P)]
+    p = api.default_params(max_iteration=iters, predict=predict, fixed_colony=ants, rng_mode=api.RNG_DEV, seed=seed)
+    s.solve(p, [0] * P, ends, streams=streams)
+    for q in range(P):
+        assert_slot(slot_state(s, q, iters), oracle_run(og, 0, ends[q], iters, predict, ants, seed, streams[q], nb), (kind, P, q))
+    s.close()
+    dg.close()
+
+
+@pytest.mark.parametrize("poison", [0, 1])
+def test_solvers_on_reused_blocks_equal_the_oracle(case, poison):
+    og, n = case
+    os.environ["WA_DEV_POISON"] = str(poison)
+    try:
+        ctx = api.Context(0)
+    finally:
+        del os.environ["WA_DEV_POISON"]
+    assert ctx.cached_bytes() == 0
+    free0, total = ctx.memory_info()
+    # a dense solver dirties its blocks; the lazy and the 26-neighbour solver that follow are built from them (shapes differ: what fits is
+    # reused, the rest allocated), then dense again on what those left behind
+    for kind, P in (("dense", 3), ("lazy", 3), ("dense", 2), ("nb26", 1), ("lazy", 4), ("dense", 3)):
+        run_once(ctx, og, n, kind, P)
+        kept = ctx.cached_bytes()
+        assert kept > 0
+        free1, _ = ctx.memory_info()
+        assert abs(free1 - free0) < (256 << 20), "kept blocks count as free"
+    ctx.trim()
+    assert ctx.cached_bytes() == 0
+    ctx.close()
+
+
+def test_reuse_is_what_happens_and_can_be_switched_off(case):
+    og, n = case
+    ctx = api.Context(0)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, 4, 32, lazy=True)
+    assert ctx.cached_bytes() == 0
+    s.close()
+    kept = ctx.cached_bytes()
+    assert kept > 4 * 6 * 4 * n                  # at least the four pheromone fields
+    s = api.AcsSolver(ctx, dg, 4, 32, lazy=True)   # the same shape again: every kept block is taken
+    assert ctx.cached_bytes() == 0
+    s.close()
+    assert ctx.cached_bytes() == kept
+    s = api.AcsSolver(ctx, dg, 2, 32, lazy=True)   # half the size: blocks that are more than 1/8 too big stay where they are
+    assert 0 < ctx.cached_bytes() <= kept
+    s.close()
+    ctx.close()
+    os.environ["WA_DEV_CACHE"] = "0"
+    try:
+        ctx = api.Context(0)
+    finally:
+        del os.environ["WA_DEV_CACHE"]
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, 4, 32, lazy=True)
+    s.close()
+    assert ctx.cached_bytes() == 0
+    ctx.close()
+
+
+def test_ref_mode_on_poisoned_blocks(case):
+    """REF mode (the libc stream, the speculated generations' buffers) on blocks filled with 0xff"""
+    og, n = case
+    os.environ["WA_DEV_POISON"] = "1"
+    try:
+        ctx = api.Context(0)
+    finally:
+        del os.environ["WA_DEV_POISON"]
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    for rep in range(2):
+        s = api.AcsSolver(ctx, dg, n_slots=1, max_colony=40)
+        s.srand(777)
+        p = api.default_params(max_iteration=40, predict=114.3, rng_mode=api.RNG_REF)
+        s.solve(p, 0, n - 1)
+        a = O.Acs(og)
+        rng = O.srand(777)
+        tr = a.solve(0, n - 1, 40, 114.3, mode=O.REF, rng=rng)
+        t = s.trace()
+        assert np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(t["steps"], tr["steps"])
+        cost, path, _ = s.result()
+        assert np.array_equal(path, a.best_path()[0]) and np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
+        st = s.rand_state()
+        assert [int(v) for v in st[:31]] == [int(v) for v in rng.r[:31]]
+        s.close()
+    ctx.close()

@@ -40,10 +40,15 @@ def main():
     exe = TD.compile_demo()
     out = "/tmp/weldacs_c5_dropin.txt"
     t0 = time.time()
+    os.environ.setdefault("WA_DEMO_TIMES", "1")
+    os.environ.setdefault("WA_TRACE_CREATE", "1")
     r = subprocess.run([exe, stl, repr(prec), "4", pf, str(24 / 0.35 * prec), out + ".graph", "dev", "7", out], capture_output=True, text=True)
     dt = time.time() - t0
     print("grid %dx%dx%d = %.1f M voxels, %d points = %d pair searches x 150 generations (24 ants): process %.2f s, rc %d" % (
         dims + (dims[0] * dims[1] * dims[2] / 1e6, P, P * (P - 1) // 2, dt, r.returncode)))
+    for l in r.stderr.splitlines():
+        if l.startswith("[demo]") or l.startswith("[weldacs]"):
+            print("   " + l.strip()[:200])
     for l in r.stdout.splitlines():
         if "shard" in l.lower() or "slots" in l.lower() or "[ACS 3D] Created" in l or "time" in l.lower():
             print("   " + l.strip()[:200])

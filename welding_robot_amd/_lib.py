@@ -33,6 +33,8 @@ SYMBOLS = {
     "wa_version": (C.c_char_p, []),
     "wa_device_count": (C.c_int, []),
     "wa_ctx_memory_info": (C.c_int, [_V, _P, _P]),
+    "wa_ctx_cached_bytes": (C.c_int, [_V, _P]),
+    "wa_ctx_trim": (C.c_int, [_V]),
     "wa_ctx_create": (C.c_int, [C.c_int, C.POINTER(_V)]),
     "wa_ctx_destroy": (None, [_V]),
     "wa_last_error": (C.c_char_p, [_V]),

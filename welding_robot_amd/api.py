@@ -53,6 +53,16 @@ class Context:
         self.check(self.lib.wa_ctx_memory_info(self.h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def cached_bytes(self):
+        """device bytes of destroyed solvers this context keeps for its next solver (wa_ctx_cached_bytes); counted as free by memory_info"""
+        b = C.c_int64()
+        self.check(self.lib.wa_ctx_cached_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def trim(self):
+        """give the kept blocks back to the driver (wa_ctx_trim)"""
+        self.check(self.lib.wa_ctx_trim(self.h))
+
     def sync(self):
         self.check(self.lib.wa_ctx_sync(self.h))
 

@@ -13,6 +13,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -22,12 +26,21 @@
 #include "traj_kernels.hpp"
 
 // ------------------------------------------------------------------ handles
+struct WaDevBlock { void *p; size_t bytes; };
 struct wa_ctx {
     int device;
     hipStream_t stream;    // every kernel of this context
     std::string err;
     hipDeviceProp_t prop;
     bool lds_attr_set = false;   // dynamic-LDS limit of the walk kernels raised on this device (wa_acs_run)
+    // Device blocks of destroyed solvers, kept for the next solver of this context (see ctx_alloc below): the driver wipes device memory
+    // that is given back, in the background at ~36 GB/s (MI355X, ROCm 7.2), and the next allocation of any size waits until ALL of it
+    // is clean -- 5.3 s after the 190 GB of a C5-sized solver were freed, against 0.1 s to clear and initialise them
+    // (profiles/r04/create_time.txt, alloc_after_free.txt).
+    std::vector<WaDevBlock> cache;
+    std::unordered_map<void *, size_t> live;   // big blocks handed out by ctx_alloc and not yet returned
+    size_t cache_bytes = 0;
+    bool cache_on = true, poison = false;      // WA_DEV_CACHE=0 / WA_DEV_POISON=1, read at wa_ctx_create
 };
 struct wa_grid {
     wa_ctx *ctx;
@@ -153,6 +166,108 @@ static int env_int(const char *name, int def)
     return v && *v ? atoi(v) : def;
 }
 
+// ------------------------------------------------------------------ the contexts' block caches
+// Solvers take their device memory through ctx_alloc / ctx_free: a block of 1 MiB or more that a solver gives back stays with the
+// context, and the next solver of a similar shape (the drop-in's pair loop creates one per searchBestPathOfPoints call, a planning
+// service one per job) gets it back without the driver's free -> wipe -> allocate round trip.  Nothing is assumed about a block's
+// contents, fresh or reused (WA_DEV_POISON=1 fills every block with 0xff bytes before it is handed out: the GPU suite passes that
+// way).  Cached bytes count as free in wa_ctx_memory_info; when the device runs out, every context's cache on that device is
+// released and the allocation retried, waiting for the wipe.  wa_ctx_trim releases a context's cache, WA_DEV_CACHE=0 switches it off.
+static std::mutex g_cache_mu;
+static std::vector<wa_ctx *> g_cache_ctxs;
+static const size_t WA_CACHE_MIN_BYTES = (size_t)1 << 20;
+
+static size_t cache_release_locked(wa_ctx *c)
+{
+    size_t freed = 0;
+    for (auto &b : c->cache) { hipFree(b.p); freed += b.bytes; }
+    c->cache.clear();
+    c->cache_bytes = 0;
+    return freed;
+}
+static size_t cache_release_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t freed = 0;
+    for (wa_ctx *o : g_cache_ctxs)
+        if (o->device == device) freed += cache_release_locked(o);
+    return freed;
+}
+static hipError_t ctx_alloc_bytes(wa_ctx *c, void **out, size_t bytes)
+{
+    if (bytes < 16) bytes = 16;
+    *out = nullptr;
+    const bool big = c->cache_on && bytes >= WA_CACHE_MIN_BYTES;
+    if (big) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        int best = -1;
+        for (int i = 0; i < (int)c->cache.size(); i++) {
+            const size_t b = c->cache[i].bytes;
+            if (b >= bytes && b - bytes <= bytes / 8 && (best < 0 || b < c->cache[best].bytes)) best = i;
+        }
+        if (best >= 0) {
+            *out = c->cache[best].p;
+            c->live[*out] = c->cache[best].bytes;
+            c->cache_bytes -= c->cache[best].bytes;
+            c->cache.erase(c->cache.begin() + best);
+        }
+    }
+    if (!*out) {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory) {
+            // every cache on this device goes back to the driver; memory that is being wiped is neither free nor allocatable for a
+            // while (hipMalloc fails rather than waits when most of the device is in that state): retry while the free figure moves
+            (void)hipGetLastError();
+            cache_release_device(c->device);
+            size_t last_free = 0;
+            int stable = 0;
+            for (int tries = 0; tries < 1200; tries++) {
+                e = hipMalloc(out, bytes);
+                if (e != hipErrorOutOfMemory) break;
+                (void)hipGetLastError();
+                size_t f = 0, t = 0;
+                if (hipMemGetInfo(&f, &t) != hipSuccess) break;
+                stable = f == last_free ? stable + 1 : 0;
+                last_free = f;
+                if (stable >= 20) break;   // a second without change: it really does not fit
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+        }
+        if (e != hipSuccess) { *out = nullptr; return e; }
+        if (big) {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            c->live[*out] = bytes;
+        }
+    }
+    if (c->poison) return hipMemsetAsync(*out, 0xff, bytes, c->stream);
+    return hipSuccess;
+}
+template <class T>
+static hipError_t ctx_alloc(wa_ctx *c, T **p, size_t count)
+{
+    return ctx_alloc_bytes(c, (void **)p, count * sizeof(T));
+}
+// (the caller has made sure that nothing in flight still uses the block: wa_acs_destroy waits for the context's streams first)
+static void ctx_free(wa_ctx *c, const void *cp)
+{
+    void *p = const_cast<void *>(cp);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = c->live.find(p);
+        if (it != c->live.end()) {
+            const size_t bytes = it->second;
+            c->live.erase(it);
+            if (c->cache_on) {
+                c->cache.push_back({p, bytes});
+                c->cache_bytes += bytes;
+                return;
+            }
+        }
+    }
+    hipFree(p);
+}
+
 extern "C" {
 
 #ifdef WA_TEST_KNOBS
@@ -176,6 +291,12 @@ int wa_ctx_create(int device_ordinal, wa_ctx **out)
         delete c;
         return WA_ERR_DEVICE;
     }
+    c->cache_on = env_int("WA_DEV_CACHE", 1) != 0;
+    c->poison = env_int("WA_DEV_POISON", 0) != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache_ctxs.push_back(c);
+    }
     *out = c;
     return WA_OK;
 }
@@ -191,14 +312,40 @@ int wa_ctx_memory_info(wa_ctx *c, int64_t *free_bytes, int64_t *total_bytes)
     if (!dev_guard_.ok) return WA_ERR_DEVICE;   // the context's device could not be made current
     size_t f = 0, t = 0;
     HIPC(c, hipMemGetInfo(&f, &t));
+    {   // blocks the contexts on this device keep for their next solver are there for the asking
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (const wa_ctx *o : g_cache_ctxs)
+            if (o->device == c->device) f += o->cache_bytes;
+    }
     if (free_bytes) *free_bytes = (int64_t)f;
     if (total_bytes) *total_bytes = (int64_t)t;
+    return WA_OK;
+}
+int wa_ctx_cached_bytes(wa_ctx *c, int64_t *bytes)
+{
+    if (!c || !bytes) return WA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    *bytes = (int64_t)c->cache_bytes;
+    return WA_OK;
+}
+int wa_ctx_trim(wa_ctx *c)
+{
+    if (!c) return WA_ERR_ARG;
+    WaDevGuard dev_guard_(c);
+    if (!dev_guard_.ok) return WA_ERR_DEVICE;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    cache_release_locked(c);
     return WA_OK;
 }
 void wa_ctx_destroy(wa_ctx *c)
 {
     if (!c) return;
     WaDevGuard dev_guard_(c);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        cache_release_locked(c);
+        g_cache_ctxs.erase(std::remove(g_cache_ctxs.begin(), g_cache_ctxs.end(), c), g_cache_ctxs.end());
+    }
     hipStreamDestroy(c->stream);
     delete c;
 }
