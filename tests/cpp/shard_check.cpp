@@ -1,7 +1,8 @@
 // shard_check.cpp -- test helper: ACS_Rank::searchBestPathOfPoints (ACSRank_3D.hpp:427-504) sharded over a device list.
-//   shard_check <stl> <precision> <wall> <points.in> <predict> <seed> <devices: "all" | "0" | "0,0" ...> <dump.txt> [slots: 0 = sized by rule]
+//   shard_check <stl> <precision> <wall> <points.in> <predict> <seed> <devices: "all" | "0" | "0,0" ...> <dump.txt> [slots: 0 = sized by rule] [calls]
 // dump: one line per ordered pair i<j: "pair i j COSTBITS len id id id ..." + the cost matrix; <dump>.shards: one line per shard
-// "shard d device pairs slots batches weight" (ACS_Rank::lastShards())
+// "shard d device pairs slots batches weight" (ACS_Rank::lastShards()); <dump>.cache: one line per call "call k bytes bytes ..." = what the
+// primary and the further shards' contexts keep after the call (wa_ctx_cached_bytes), then "trimmed bytes ..." after trimDeviceMemory()
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,8 +28,25 @@ int main(int argc, char **argv)
         for (char *t = strtok(argv[7], ","); t; t = strtok(NULL, ",")) d.push_back(atoi(t));
         sp.setDevices(d);
     }
-    sp.searchBestPathOfPoints((float)atof(argv[5]), argv[4], "");
-    if (sp.lastStatus() != WA_OK) return 4;
+    const int calls = argc > 10 ? atoi(argv[10]) : 1;
+    FILE *fc = fopen((std::string(argv[8]) + ".cache").c_str(), "w");
+    if (!fc) return 5;
+    auto kept = [&](const char *tag, int k) {
+        fprintf(fc, "%s %d", tag, k);
+        int64_t b = 0;
+        if (weldacs_dropin::ctx_slot() && wa_ctx_cached_bytes(weldacs_dropin::ctx_slot(), &b) == WA_OK) fprintf(fc, " %lld", (long long)b);
+        for (auto &sc : weldacs_dropin::shard_slots())
+            if (sc.ctx && wa_ctx_cached_bytes(sc.ctx, &b) == WA_OK) fprintf(fc, " %lld", (long long)b);
+        fprintf(fc, "\n");
+    };
+    for (int k = 0; k < calls; k++) {
+        sp.searchBestPathOfPoints((float)atof(argv[5]), argv[4], "");
+        if (sp.lastStatus() != WA_OK) return 4;
+        kept("call", k);
+    }
+    sp.trimDeviceMemory();
+    kept("trimmed", calls);
+    fclose(fc);
     FILE *fp = fopen(argv[8], "w");
     if (!fp) return 5;
     const int P = (int)sp.route_points.size();

@@ -150,6 +150,34 @@ def test_pair_loop_sharded_over_contexts_is_shard_invariant():
 
 
 @pytest.mark.gpu
+def test_pair_loop_called_again_reuses_what_its_contexts_kept():
+    """searchBestPathOfPoints three times on one object, three shards on one GPU: the shards' contexts live on between the calls and keep the
+    device blocks of the solvers each call destroys (wa_ctx_cached_bytes), so the second and third call allocate nothing new -- what is kept
+    stops growing -- and every call's costs and paths are those of a single call; trimDeviceMemory() hands everything back."""
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
+                        os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
+    outs = {}
+    for calls in (1, 3):
+        out = "/tmp/weldacs_again_%d.txt" % calls
+        rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", "0,0,0", out, "0", str(calls)],
+                            capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
+        outs[calls] = open(out, "rb").read()
+        rows = [l.split() for l in open(out + ".cache")]
+        kept = [[int(v) for v in r_[2:]] for r_ in rows if r_[0] == "call"]
+        assert len(kept) == calls and all(len(k) == 3 for k in kept)            # primary + two further shard contexts
+        assert all(b > 0 for b in kept[0][1:])                                   # the further shards' solvers were destroyed: their blocks are kept
+        for k in kept[1:]:
+            assert k[1:] == kept[0][1:], kept                                    # ... and taken and given back by every further call: nothing new
+        assert [int(v) for v in rows[-1][2:]] == [0, 0, 0] and rows[-1][0] == "trimmed"
+    assert outs[3] == outs[1] and outs[1].count(b"pair ") == 10
+
+
+@pytest.mark.gpu
 def test_pair_loop_deals_whole_end_point_groups_when_there_are_enough():
     """Ten weld points = 45 pair searches, 9 end-point groups: with two contexts (9 >= 4 x 2) the C++ pair loop deals WHOLE groups
     longest-first (every end point lives on one shard), with one context nothing is dealt; costs and paths are the same bytes."""

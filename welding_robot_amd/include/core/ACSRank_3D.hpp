@@ -134,6 +134,8 @@ public:
     // Default: the primary context's device, then every other visible device (wa_device_count()).  An ordinal may be listed
     // twice (two contexts on one GPU).
     void setDevices(const std::vector<int> &ordinals) { devices = ordinals; devices_set = true; }
+    // The contexts keep the device blocks of the solvers of earlier calls for the next call (wa_ctx_cached_bytes); this hands them back.
+    void trimDeviceMemory() { weldacs_dropin::trim_device_memory(); }
     int lastStatus() const { return last_status; }
     const std::vector<float> &cost_matrix() const { return costs; }
 
@@ -328,7 +330,8 @@ public:
             std::vector<wa_acs *> ss(D, (wa_acs *)NULL);
             cs[0] = weldacs_dropin::context(); ss[0] = solver;
             for (int d = 1; d < D; d++) {
-                int rc = wa_ctx_create(devs[d], &cs[d]);
+                int rc = WA_OK;
+                cs[d] = weldacs_dropin::shard_context(d, devs[d], &rc);   // kept for the process, with the blocks its solvers give back
                 if (rc == WA_OK) rc = wa_grid_from_occupancy(cs[d], fr.data(), rangeX, rangeY, rangeZ, ax.data(), ay.data(), az.data(), precision, wall, &gs[d]);
                 if (rc == WA_OK) {   // sized on the shard's own device, which may be shared with another shard
                     shard_slots[d] = slots_for(cs[d], predict_path_len, (int)shard_pairs[d].size(), shard_pairs[d], pairs);
@@ -346,7 +349,6 @@ public:
             for (int d = 1; d < D; d++) {
                 if (ss[d]) wa_acs_destroy(ss[d]);
                 if (gs[d]) wa_grid_destroy(gs[d]);
-                if (cs[d]) wa_ctx_destroy(cs[d]);
             }
         }
         for (int d = 0; d < D; d++)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <iostream>
+#include <vector>
 
 #include "weldacs.h"
 
@@ -23,6 +24,28 @@ inline wa_ctx *context()
         }
     }
     return c;
+}
+// Contexts of the further shards of ACS_Rank::searchBestPathOfPoints (shard 0 runs on the primary context): one per shard index, kept
+// for the process like the primary, so that the device blocks a shard's solver gives back serve the same shard of the next call
+// (wa_ctx_cached_bytes).  A shard that moves to another device gets a new context.
+struct ShardCtx { wa_ctx *ctx; int device; };
+inline std::vector<ShardCtx> &shard_slots() { static std::vector<ShardCtx> v; return v; }
+inline wa_ctx *shard_context(int shard, int device, int *rc_out)
+{
+    std::vector<ShardCtx> &v = shard_slots();
+    if ((int)v.size() <= shard) v.resize((size_t)shard + 1, ShardCtx{nullptr, -1});
+    ShardCtx &s = v[(size_t)shard];
+    if (s.ctx && s.device != device) { wa_ctx_destroy(s.ctx); s.ctx = nullptr; }
+    int rc = WA_OK;
+    if (!s.ctx) { rc = wa_ctx_create(device, &s.ctx); s.device = device; if (rc != WA_OK) s.ctx = nullptr; }
+    if (rc_out) *rc_out = rc;
+    return s.ctx;
+}
+// hand the device blocks every context of the drop-in keeps back to the driver (before another library needs the memory)
+inline void trim_device_memory()
+{
+    if (ctx_slot()) wa_ctx_trim(ctx_slot());
+    for (ShardCtx &s : shard_slots()) if (s.ctx) wa_ctx_trim(s.ctx);
 }
 // the reference's process-global rand() stream (Q2), carried between ACS_Rank and ACS_GTSP
 inline int32_t *rand_state() { static int32_t st[36]; return st; }
