@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
     // their latency-bound work hides under the sweep blocks that follow
     if ((int32_t)blockIdx.x >= MB) {  // ---- sweep: dst = src * rho (same body as k_evaporate)
+#ifdef WA_TEST_KNOBS
+        if (sweep_nt & 0x100) return;   // timing aid (tools/fused_parts.py): the launch without its sweep
+#endif
         if (!SPARSE) {
             wa_sweep_body(src_base + (int64_t)slot * D.pher_stride, dst_base + (int64_t)slot * D.pher_stride, (int64_t)NB * D.d.n, R.rho,
                           (int32_t)blockIdx.x - MB, E, sweep_nt);
@@ -457,6 +460,9 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
     const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
     if (o > n_dep) return;
+#ifdef WA_TEST_KNOBS
+    if (sweep_nt & 0x200) return;       // timing aid: the launch without the marks (nothing is deposited: the colony keeps exploring)
+#endif
     const int32_t a = s_perm[o - 1];
     const int32_t len = s_len[a];
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
