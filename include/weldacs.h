@@ -55,7 +55,8 @@ int wa_ctx_memory_info(wa_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
  * reference never frees anything (SURVEY 8(b) ownership) and creates its search once per process; a host that runs
  * searchBestPathOfPoints per job would otherwise pay the driver's wipe of the freed memory before every re-allocation (seconds for
  * a C5-sized solver).  Kept bytes count as free in wa_ctx_memory_info and go back to the driver when the device runs out, on
- * wa_ctx_trim and with the context.  WA_DEV_CACHE=0 in the environment switches the mechanism off. */
+ * wa_ctx_trim and with the context.  Other PROCESSES on the same GPU cannot have those bytes until then: a host that shares its GPU
+ * trims after its last job.  WA_DEV_CACHE=0 in the environment switches the mechanism off. */
 int wa_ctx_cached_bytes(wa_ctx *ctx, int64_t *bytes);
 int wa_ctx_trim(wa_ctx *ctx);
 /* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling

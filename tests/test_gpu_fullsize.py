@@ -174,6 +174,11 @@ def test_c5_full_size_pair_planning_and_seam_order(ctx):
     assert tour["L"][0] == o["L"] and np.array_equal(tour["edges"][0], o["edges"]) and int(tour["iters"][0]) == o["iters"]
     order = [int(e[0]) for e in tour["edges"][0]]
     assert sorted(order) == list(range(P))
+    # the context keeps the blocks of the solvers destroyed above for its next solver (wa_ctx_cached_bytes); the tests below start OTHER
+    # processes on this GPU, which would wait for that memory (bench.py: wait_for_device_memory)
+    assert ctx.cached_bytes() > (50 << 30)
+    ctx.trim()
+    assert ctx.cached_bytes() == 0
 
 
 # ------------------------------------------------------------------ C4 with the ranks a 1-GPU box has
