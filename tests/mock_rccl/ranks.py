@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""One rank of tests/test_gpu_mock_ranks.py: every exchange of the library's communicator (wa_comm_*, csrc/host_comm.inc) with world > 1 on
+ONE GPU, RCCL replaced by tests/mock_rccl (LD_PRELOAD).  Writes what it saw to <out>.rank<r>.npz; the parent test holds the ranks'
+files against each other.
+
+    RANK=r WORLD_SIZE=w MASTER_PORT=p LD_PRELOAD=libmock_rccl.so python tests/mock_rccl/ranks.py <out>"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from welding_robot_amd import api  # noqa: E402
+from welding_robot_amd import dist as wd  # noqa: E402
+from test_gpu_edges import box_grid  # noqa: E402
+
+
+def main():
+    out = sys.argv[1]
+    rank, _, world = wd.env_rank()
+    ctx = api.Context(0)                       # every rank on the one GPU
+    uid = wd.ship_unique_id(rank, world, api.Comm.unique_id)
+    assert bytes(uid[:4]) == b"mock", "librccl itself is answering: LD_PRELOAD did not take"
+    comm = api.Comm(ctx, rank, world, np.frombuffer(uid, np.uint8))
+    comm.barrier()
+    # ---- (1) the global best per generation with its owner: two searches per rank, different streams on every rank
+    og = box_grid(36, 32, 40, occ_prob=0.12, seed=5)
+    n = 36 * 32 * 40
+    og.free[0] = og.free[-1] = 1
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    K, chunk, ants = 24, 8, 32
+    s = api.AcsSolver(ctx, dg, 2, ants)
+    p = api.default_params(max_iteration=K, predict=ants / 0.35, fixed_colony=ants, rng_mode=api.RNG_DEV, seed=31)
+    s.init_pheromone(1.0)
+    s.begin(p, [0, 0], [n - 1, n - 1], streams=[10 * rank + 1, 10 * rank + 2])
+    for g0 in range(0, K, chunk):
+        s.run(chunk)
+        comm.allreduce_best(s, g0, chunk)     # asynchronous in the library; the next chunk is enqueued behind it
+    s.sync()
+    cost, owner_rank, owner_slot = comm.read_best_owner(0, K)
+    mine = np.stack([s.trace(q)["bestL"][:K] for q in range(2)])
+    # ---- (2) host-side reductions
+    red = {op: comm.allreduce([rank + 1.5, -float(rank), 2.0], op) for op in ("min", "max", "sum")}
+    # ---- (3) pair costs to every rank: ragged -- rank r owns r pairs (rank 0 none), indices interleaved
+    n_total = sum(range(world)) + 2            # two entries nobody owns
+    start = sum(range(rank))
+    idx = [start + i for i in range(rank)]
+    costs = [100.0 * rank + i + 0.25 for i in range(rank)]
+    vec = comm.allgather_costs(idx, costs, n_total, fill=-1.0)
+    # ---- (4) paths to a root that is NOT rank 0: ragged, one empty path, the last rank owns nothing
+    root = world - 1
+    paths = {}
+    if rank != world - 1 or world == 1:
+        for i in range(rank + 2):
+            paths[1000 * rank + i] = np.arange(7 * rank + i, 7 * rank + i + (0 if i == 1 else 5 + 3 * i), dtype=np.int32)
+    got = comm.gather_paths(paths, root=root)
+    comm.barrier()
+    np.savez(out + ".rank%d.npz" % rank, cost=cost, owner_rank=owner_rank, owner_slot=owner_slot, mine=mine,
+             red_min=red["min"], red_max=red["max"], red_sum=red["sum"], vec=vec,
+             got_keys=np.array(sorted(got), np.int64), got_ids=np.concatenate([got[k] for k in sorted(got)] + [np.zeros(0, np.int32)]),
+             got_lens=np.array([len(got[k]) for k in sorted(got)], np.int64),
+             sent_keys=np.array(sorted(paths), np.int64), sent_ids=np.concatenate([paths[k] for k in sorted(paths)] + [np.zeros(0, np.int32)]),
+             sent_lens=np.array([len(paths[k]) for k in sorted(paths)], np.int64))
+    comm.close()
+    s.close()
+    dg.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,20 @@ def test_library_links_rccl_itself_and_the_cpp_host_compiles_without_torch():
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
 
 
+def test_the_mock_stands_in_for_every_rccl_entry_point_the_library_calls():
+    """tests/mock_rccl (what tests/test_gpu_mock_ranks.py puts in front of librccl to run world > 1 on one GPU) compiles here and exports
+    exactly the RCCL symbols libweldacs.so imports: a new ncclXxx call in csrc/host_comm.inc cannot slip past the multi-rank tests"""
+    import test_gpu_mock_ranks as M
+    mock = M.build_mock()
+
+    def syms(path, kind):
+        r = subprocess.run(["nm", "-D", path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return {l.split()[-1] for l in r.stdout.splitlines() if (" %s nccl" % kind) in l}
+    wanted, have = syms(_lib.LIB_PATH, "U"), syms(mock, "T")
+    assert len(wanted) >= 11 and wanted <= have, wanted - have
+
+
 @pytest.mark.gpu
 def test_allreduce_best_with_one_rank_really_reduces_and_overlaps():
     """two searches in flight on one solver: global_best[g] = MIN over the active slots (k_min_over_slots) then
@@ -148,10 +162,15 @@ def test_best_key_packs_cost_and_owner_in_one_orderable_word():
 def test_cpp_multistart_host_equals_the_oracle_trace():
     """examples/multistart_rccl.cpp (C4 from a C++ host: thread + wa_ctx + wa_comm per device) on the devices this box has:
     every rank's local history equals the oracle's DEV-mode run of that rank's problem, the global history is their MIN."""
+    check_multistart("all")
+
+
+def check_multistart(devices, env=None, want_ranks=None):
+    """(also run by tests/test_gpu_mock_ranks.py with three ranks on one GPU, RCCL replaced by the mock)"""
     compile_multistart()
     n, ants, K = 48, 64, 60
     out = "/tmp/weldacs_ms_%d.txt" % os.getpid()
-    r = subprocess.run([EXE, str(n), str(ants), str(K), "all", out], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, str(n), str(ants), str(K), devices, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout + r.stderr
     loc, glob, owner, owner_path = {}, {}, {}, None
     for line in open(out):
@@ -164,7 +183,7 @@ def test_cpp_multistart_host_equals_the_oracle_trace():
         elif t[0] == "owner_path":
             owner_path = (int(t[1]), [int(v) for v in t[3:3 + int(t[2])]])
     W = len(loc)
-    assert W >= 1 and len(glob) == K
+    assert W >= 1 and len(glob) == K and (want_ranks is None or W == want_ranks)
     hist, best_paths = [], []
     for rk in range(W):
         og = O.synth_grid(n, seed=2024 + rk, occ_prob=0.10)
