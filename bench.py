@@ -458,7 +458,13 @@ def main():
     dist_on = world > 1 or (os.environ.get("WA_FORCE_DIST") == "1" and "RANK" in os.environ)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # (WA_BENCH_BACKEND=gloo: torch's own collectives over gloo on host tensors -- how tests/test_gpu_mock_ranks.py runs this very path with two
+        #  ranks on ONE GPU, where RCCL refuses a second rank; the library's exchange then goes through the test's RCCL stand-in)
+        if os.environ.get("WA_BENCH_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if dist_on and dist.get_backend() == "gloo" else dev   # where torch's own small collectives live
     ctx = api.Context(local_rank)  # raises if libweldacs.so or the device is missing: no fallback
     mem_wait_s = wait_for_device_memory(ctx)
     n, K, W = args.grid, args.steps, args.warmup
@@ -492,7 +498,7 @@ def main():
     use_torch_ar = dist_on and os.environ.get("WA_BENCH_TORCH_ALLREDUCE") == "1"
     comm = None
     if dist_on and not use_torch_ar:
-        uid = torch.from_numpy(api.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+        uid = torch.from_numpy(api.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(cdev)
         dist.broadcast(uid, src=0)
         try:
             comm = api.Comm(ctx, rank, world, uid.cpu().numpy())
@@ -501,7 +507,7 @@ def main():
         except api.WeldacsError as e:   # (never seen; every rank must take the same path, so the ranks agree on it below)
             print("[bench] rank %d: wa_comm_create failed (%s)" % (rank, e), file=sys.stderr)
             comm, ok = None, 0.0
-        if wd.max_over_ranks(-ok, dev) != -1.0:   # some rank failed: everybody exchanges through torch.distributed instead
+        if wd.max_over_ranks(-ok, cdev) != -1.0:   # some rank failed: everybody exchanges through torch.distributed instead
             if comm is not None:
                 comm.close()
             comm, use_torch_ar = None, True
@@ -539,8 +545,8 @@ def main():
             w.wait()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = wd.max_over_ranks(elapsed, dev)
-    total_gens = wd.sum_over_ranks(K, dev)
+    elapsed = wd.max_over_ranks(elapsed, cdev)
+    total_gens = wd.sum_over_ranks(K, cdev)
     ctx.check(ctx.lib.wa_acs_debug_counters(solver.h, dbg16.ctypes.data, 0))
     stragglers = {"handed_over": int(dbg16[9]), "finished_by_resume_blocks": int(dbg16[7]),
                   "note": "ants that could no longer be among the depositing ranks left their walk launch at one of the loop's checks and were finished "
@@ -556,10 +562,10 @@ def main():
         if world == 1:
             assert np.array_equal(glob.view(np.uint32), trace["bestL"].view(np.uint32))
         else:   # ... and somebody's local best: the MIN over ranks of the local histories, computed the slow way
-            allh = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(world)]
-            dist.all_gather(allh, torch.from_numpy(np.ascontiguousarray(trace["bestL"], np.float32)).to(dev))
+            allh = [torch.empty(K, dtype=torch.float32, device=cdev) for _ in range(world)]
+            dist.all_gather(allh, torch.from_numpy(np.ascontiguousarray(trace["bestL"], np.float32)).to(cdev))
             assert np.array_equal(torch.stack(allh).min(0).values.cpu().numpy().view(np.uint32), glob.view(np.uint32)), "RCCL MIN != MIN of the gathered histories"
-    best_all = wd.max_over_ranks(-float(cost), dev) * -1.0  # min over ranks
+    best_all = wd.max_over_ranks(-float(cost), cdev) * -1.0  # min over ranks
     if rank == 0:
         # ---- the roofline kernel = the launch of the TIMED loop that carries the evaporation sweep (k_evap_rank_mark: 4096 sweep
         # blocks + the rank / mark blocks), per-dispatch HIP events on the library's stream over the timed region

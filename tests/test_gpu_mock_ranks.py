@@ -40,7 +40,7 @@ def run_ranks(world, argv, timeout=240):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60")
+                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60", WA_BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -132,3 +132,19 @@ def test_cpp_multistart_host_with_three_ranks_on_one_gpu():
     shutil.rmtree(MOCK_DIR, ignore_errors=True)
     test_comm.check_multistart("0,0,0", env={"LD_PRELOAD": MOCK, "MOCK_RCCL_DIR": MOCK_DIR, "MOCK_RCCL_TIMEOUT_S": "60"}, want_ranks=3)
     shutil.rmtree(MOCK_DIR, ignore_errors=True)
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 as the round driver launches it (RANK / WORLD_SIZE / MASTER_* in the environment), both ranks on the one GPU: the library's
+    exchange through the mock, torch's own barrier and small reductions over gloo (WA_BENCH_BACKEND=gloo; on a multi-GPU node both are RCCL).
+    bench.py itself asserts that the reduced global-best history is the MIN of the ranks' gathered histories; here: one JSON line, from rank 0,
+    that counts both ranks' generations and names the owner of the final global best."""
+    outs = run_ranks(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3"], timeout=400)
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][1].splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and "wa_acs_allreduce_best" in d["config"]["global_best_allreduce"]
+    assert abs(d["value"] - 2 * 30 / (d["ms_per_step"] * 30 * 1e-3)) < 1e-6 * d["value"]      # whole-job rate: both ranks' generations over the slowest rank's time
+    assert d["global_best_owner"][0] in (0, 1) and d["global_best_owner"][1] == 0
+    assert d["best_cost_all_ranks"] <= d["best_cost"]
+    assert "cpu_baseline" not in d and "multi_start" not in d          # N > 1: the timed job only
