@@ -1,5 +1,6 @@
 """Thin numpy-facing wrappers over the C ABI (include/weldacs.h) for tests and bench.py.
 All compute happens in libweldacs.so's HIP kernels; this file only marshals pointers."""
+import atexit
 import ctypes as C
 import weakref
 
@@ -13,6 +14,21 @@ def _ptr(a):
     return a.ctypes.data if a is not None else None
 
 
+# Contexts still open when the interpreter exits are closed HERE, children first, while the HIP / RCCL runtimes are still up: left to
+# __del__ during interpreter teardown the destroy calls can arrive after those runtimes' own exit handlers have run (seen on ROCm 7.2 as
+# "terminate called after throwing std::bad_variant_access" from a communicator destroyed that late).
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_contexts():
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:   # noqa: BLE001 -- exit path: nothing useful can be done with an error here
+            pass
+
+
 class Context:
     def __init__(self, device=0, lib_path=None):
         self.lib = L.load(lib_path)
@@ -22,6 +38,7 @@ class Context:
             raise WeldacsError(rc, "wa_ctx_create(%d) failed: no usable HIP device" % device)
         self.h = h
         self._children = weakref.WeakSet()  # grids / solvers must be destroyed before the context
+        _live_contexts.add(self)
 
     def check(self, rc):
         if rc:
