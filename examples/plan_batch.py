@@ -51,11 +51,17 @@ def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=
                            rng_mode=api.RNG_DEV, seed=seed)
     cost = np.zeros((P, P), np.float64)
     paths = {}
+    plan.last_batch_s = []                             # seconds per batch: solve / reset / read-back (tools/walk_direct_ab.py --batches)
     for b0 in range(0, len(mine), slots):
         idx = mine[b0:b0 + slots]
+        tb = [time.perf_counter()]
         solver.solve(p, [point_ids[pairs[k][0]] for k in idx], [point_ids[pairs[k][1]] for k in idx], streams=idx)
+        tb.append(time.perf_counter())
         solver.reset_pheromone(1.0)  # reset() between problems (:481)
+        tb.append(time.perf_counter())
         costs, ids_all = solver.results(len(idx))      # one round trip for the whole batch
+        tb.append(time.perf_counter())
+        plan.last_batch_s.append([round(tb[i + 1] - tb[i], 4) for i in range(3)])
         for q, k in enumerate(idx):
             i, j = pairs[k]
             cost[i, j] = cost[j, i] = costs[q]

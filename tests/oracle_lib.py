@@ -9,7 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "libweld_oracle.so")
+# WELD_ORACLE_LIB: another build of the same source (oracle/Makefile `asan`: tests/test_sanitizers.py)
+LIB_PATH = os.environ.get("WELD_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libweld_oracle.so")
 REF_BIN = os.path.join(ORACLE_DIR, "_ref", "ref_harness")
 
 REF, DEV = 0, 1
@@ -38,6 +39,8 @@ class GtspParams(C.Structure):
 
 
 def build():
+    if os.environ.get("WELD_ORACLE_LIB"):
+        return
     src = [os.path.join(ORACLE_DIR, f) for f in ("weld_oracle.c", "weld_oracle.h")]
     if (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "libweld_oracle.so"], stdout=subprocess.DEVNULL)

@@ -194,19 +194,21 @@ def test_every_ant_of_a_generation_matches_the_oracle(ctx):
 
 
 def test_hand_scheduled_walk_loop_equals_the_compiler_scheduled_one(ctx):
-    """WA_WALK_ASM=0 keeps the C++ loop; WA_WALK_WARM=0 / 1 forces the hand-scheduled loop without / with its touch loads (the
-    product picks by launch size): all must give the same ants, the same field, the same trace."""
+    """WA_WALK_ASM=0 keeps the C++ loop; WA_WALK_WARM=0 / 1 forces the hand-scheduled loop without / with its touch loads,
+    WA_WALK_DIRECT=1 the loop without any look-ahead (the product picks by launch size): all must give the same ants, the
+    same field, the same trace."""
     og = box_grid(24, 24, 24, occ_prob=0.1, seed=8)
     og.free[0] = og.free[-1] = 1
     n = 24 ** 3
     res = []
-    for name, knob in (("WA_WALK_ASM", "1"), ("WA_WALK_ASM", "0"), ("WA_WALK_WARM", "0"), ("WA_WALK_WARM", "1")):
-        os.environ[name] = knob
+    for knobs in (dict(WA_WALK_ASM="1"), dict(WA_WALK_ASM="0"), dict(WA_WALK_WARM="0", WA_WALK_DIRECT="0"), dict(WA_WALK_WARM="1"), dict(WA_WALK_DIRECT="1")):
+        os.environ.update(knobs)
         try:
             s, a, t = run_both(ctx, og, 0, n - 1, 25, 200.0, fixed=64, seed=77)
             res.append((s.ants(), s.pheromone(), t))
         finally:
-            del os.environ[name]
+            for k in knobs:
+                del os.environ[k]
     (x, px, tx) = res[0]
     for (y, py, ty) in res[1:]:
         assert np.array_equal(x[1], y[1]) and np.array_equal(bits(x[0]), bits(y[0])) and np.array_equal(bits(px), bits(py))

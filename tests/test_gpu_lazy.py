@@ -120,6 +120,38 @@ def test_lazy_init_then_reset_switches_mode(ctx):
         assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), step
 
 
+@pytest.mark.parametrize("faces", ["1", "0"])
+def test_lazy_mode_switch_with_p0_unchanged_rewrites_the_faces_only(ctx, faces, monkeypatch):
+    """initFromGridMap (out-of-bounds edges 0) -> reset() (every edge p0) -> ... with the SAME p0: only the out-of-bounds edges of the six
+    lattice faces differ between the two modes (ACSRank_3D.hpp:389-403 vs :307-315), so the switch rewrites those and the dirty records
+    (k_lazy_faces) instead of the whole field.  Odd dimensions, corner-to-corner and face-hugging searches in three slots; the whole field
+    of every slot against the oracle after every switch, and the same with the full pass (WA_LAZY_FACES=0)."""
+    from test_gpu_edges import box_grid
+    monkeypatch.setenv("WA_LAZY_FACES", faces)
+    nx, ny, nz = 13, 9, 7
+    og = box_grid(nx, ny, nz, occ_prob=0.05, seed=5)
+    n = nx * ny * nz
+    og.free[[0, n - 1, nx - 1, n - nx, (nz // 2) * nx * ny]] = 1
+    dg = dgrid_from(ctx, og)
+    starts, ends = [0, nx - 1, (nz // 2) * nx * ny], [n - 1, n - nx, n - 1]
+    s = api.AcsSolver(ctx, dg, 3, 12, lazy=True)
+    p = api.default_params(max_iteration=12, predict=40.0, fixed_colony=12, rng_mode=api.RNG_DEV, seed=11)
+    oracles = [O.Acs(og) for _ in starts]
+    for rnd, step in enumerate(("created", "reset", "reset", "init", "reset", "carry", "init")):
+        if step == "reset":
+            s.reset_pheromone(1.0)
+            for a in oracles:
+                a.reset(1.0)
+        elif step == "init":
+            s.init_pheromone(1.0)
+            oracles = [O.Acs(og) for _ in starts]
+        s.solve(p, starts, ends, streams=[10 * rnd + q for q in range(3)])
+        for q, a in enumerate(oracles):
+            a.solve(starts[q], ends[q], 12, 40.0, fixed_colony=12, mode=O.DEV, seed=11, stream=10 * rnd + q)
+            assert np.array_equal(bits(s.pheromone(q)), bits(a.pheromone())), (step, rnd, q)
+    s.close()
+
+
 def test_lazy_rho_change_and_long_carry_over(ctx):
     """Consecutive solves WITHOUT reset, with different rho and odd generation counts: the pending evaporations of
     deposited records (at most 16 are ever outstanding) are applied with the rho they belong to."""

@@ -361,9 +361,12 @@ def test_random_medium_search_equals_the_oracle(ctx, seed):
 
 # ------------------------------------------------------------------ the same random searches down the other code paths
 KNOBS = [dict(WA_WALK_ASM="0"),                         # the compiler-scheduled loop instead of the hand-scheduled one
-         dict(WA_WALK_WARM="0"),                        # no touch loads (the saturated-launch variant of the loop)
+         dict(WA_WALK_WARM="0", WA_WALK_DIRECT="0"),    # look-ahead without touch loads
+         dict(WA_WALK_DIRECT="1"),                      # no look-ahead at all (the saturated-launch variant of the loop)
          dict(WA_HASH_LOG2="6"),                        # a 64-entry tabu table: probe chains, spill to the global bitmap
-         dict(WA_HASH_LOG2="8", WA_WALK_WARM="0"),
+         dict(WA_HASH_LOG2="8", WA_WALK_WARM="0", WA_WALK_DIRECT="0"),
+         dict(WA_HASH_LOG2="8", WA_WALK_DIRECT="1"),
+         dict(WA_WALK_DIRECT="1", WA_REENTRY_STABLE="1"),
          dict(WA_REENTRY="0"),                          # no rejoin watch
          dict(WA_REENTRY_STABLE="1"),                   # ... armed after one stable generation
          dict(WA_EVAP_BLOCKS="7"), dict(WA_LAZY_BLOCKS="3")]   # odd sweep / background-pass grids

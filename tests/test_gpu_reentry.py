@@ -50,7 +50,9 @@ KNOBS = {
     # must count steps, not evaluation passes, or an ant on the best path never gets its step done
     "tiny hash, long probe chains": dict(WA_REENTRY_STABLE="0", WA_HASH_LOG2="7"),
     "tiny hash, hand back anywhere": dict(WA_REENTRY_STABLE="0", WA_HASH_LOG2="7", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="2"),
-    "no touch loads (the loop of saturated launches)": dict(WA_REENTRY_STABLE="0", WA_WALK_WARM="0", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="5"),
+    "no touch loads": dict(WA_REENTRY_STABLE="0", WA_WALK_WARM="0", WA_WALK_DIRECT="0", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="5"),
+    "no look-ahead (the loop of saturated launches)": dict(WA_REENTRY_STABLE="0", WA_WALK_DIRECT="1", WA_REENTRY_ANYWHERE="1", WA_REENTRY_HOLD="5"),
+    "no look-ahead, tiny hash": dict(WA_REENTRY_STABLE="0", WA_WALK_DIRECT="1", WA_HASH_LOG2="7"),
     "product default": dict(),
     "off": dict(WA_REENTRY="0"),
 }
@@ -65,7 +67,7 @@ def test_every_ant_every_path_word_equals_the_oracle(ctx_product, ctx_knobs, kno
     og = O.synth_grid(n, seed=77, occ_prob=occ)
     free = np.nonzero(og.free)[0]
     sid, eid = int(free[0]), int(free[-1])
-    old = {k: os.environ.get(k) for k in ("WA_REENTRY", "WA_REENTRY_STABLE", "WA_REENTRY_ANYWHERE", "WA_REENTRY_HOLD", "WA_HASH_LOG2", "WA_WALK_WARM")}
+    old = {k: os.environ.get(k) for k in ("WA_REENTRY", "WA_REENTRY_STABLE", "WA_REENTRY_ANYWHERE", "WA_REENTRY_HOLD", "WA_HASH_LOG2", "WA_WALK_WARM", "WA_WALK_DIRECT")}
     os.environ.update(KNOBS[knobs])
     try:
         dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)

@@ -627,6 +627,39 @@ __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0,
         stamp[id] = 0;
     }
 }
+// The two init modes (initFromGridMap: out-of-bounds edges 0, ACSRank_3D.hpp:389-403; reset(): every edge pheromone_0, :307-315) differ
+// ONLY in the out-of-bounds edges, and those exist on the six faces of the lattice only: a lazy slot that changes mode with p0 unchanged
+// (the first reset() behind initFromGridMap -- every pair-planning run) rewrites 2(nx ny + nx nz + ny nz) floats instead of 6 N
+// (256^3: 0.4 M instead of 100 M per slot; 224 slots: 70 ms of the first batch's read-back).  Thread per (face voxel): its one edge that
+// leaves the lattice through that face, the value k_init_pheromone would store (sign set: never admissible).  grid.y = slots.
+__global__ __launch_bounds__(256) void k_lazy_faces(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
+{
+    const int32_t slot = slot0 + blockIdx.y;
+    const int64_t nx = D.d.nx, ny = D.d.ny, nz = D.d.nz, nxy = D.d.nxy;
+    const int64_t fz = nx * ny, fy = nx * nz, fx = ny * nz;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * (fz + fy + fx)) return;
+    int64_t id;
+    int k;
+    if (t < 2 * fz) {            // z = 0 (edge 0: z-1) and z = nz-1 (edge 5: z+1)
+        const bool hi = t >= fz;
+        id = (hi ? t - fz : t) + (hi ? (nz - 1) * nxy : 0);
+        k = hi ? 5 : 0;
+    } else if ((t -= 2 * fz) < 2 * fy) {   // y = 0 (edge 1) and y = ny-1 (edge 4)
+        const bool hi = t >= fy;
+        const int64_t q = hi ? t - fy : t;
+        id = (q / nx) * nxy + (hi ? (ny - 1) * nx : 0) + q % nx;
+        k = hi ? 4 : 1;
+    } else {                     // x = 0 (edge 2) and x = nx-1 (edge 3)
+        t -= 2 * fy;
+        const bool hi = t >= fx;
+        const int64_t q = hi ? t - fx : t;
+        id = (q / ny) * nxy + (q % ny) * nx + (hi ? nx - 1 : 0);
+        k = hi ? 3 : 2;
+    }
+    const float v = mode == 1 ? p0 : 0.f;
+    D.pher[(int64_t)slot * D.pher_stride + id * 6 + k] = -v;
+}
 // bring every deposited record current (before a solve that evaporates with a different rho: the pending
 // multiplications belong to the old one).  grid.y = slots.
 __global__ __launch_bounds__(256) void k_lazy_flush(WaAcsDev D, float rho_old)

@@ -525,7 +525,7 @@ __device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
     if (lane == 0) reinterpret_cast<int32_t *>(tab4)[1 << hash_log2] = WA_HASH_SENTINEL;
 }
 
-template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
+template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t &rng_rs, int32_t &rng_f, int32_t &rng_b,
@@ -690,7 +690,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         const int32_t dbg_prefix = st.len;
 #endif
         for (;;) {
-            wa_walk_fast_asm<SPARSE ? 3 : 2, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+            wa_walk_fast_asm<SPARSE ? 3 : 2, WARM, false, DIRECT>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                              D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold,
                                              SPARSE ? nullptr : sg.arr_len, cut_n);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
@@ -761,7 +761,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                                         &rng_rs, &rng_f, &rng_b);
     } else if (st.len < fast_limit && use_asm) {
         WA_PHASE(8);
-        wa_walk_fast_asm<SPARSE ? 1 : 0, WARM>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+        wa_walk_fast_asm<SPARSE ? 1 : 0, WARM, false, DIRECT>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                  D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr,
                                  nullptr, 0, 0, SPARSE ? nullptr : sg.arr_len, cut_n);
         if (!st.done && st.reason == 5) {
@@ -953,7 +953,8 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 // REJ: the kernel carries the rejoin watch + re-entry onto the replay track.  The host launches the instantiation without it for
 // the first generations of a search, in which the watch cannot be armed yet (it waits for a best path that has been stable for
 // WA_REENTRY_STABLE generations): the mere presence of that code costs the exploratory walk 1.5 % (187 vs 190 us per launch).
-template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true>
+// DIRECT: the hand-scheduled loop without look-ahead (saturated launches; see walk_loop_gfx950.hpp, W = DIRECT)
+template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         int32_t f0 = 0, b0 = 0, rs0 = 0;
-        wa_walk_one<1, true, false, WARM, false>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
+        wa_walk_one<1, true, false, WARM, false, DIRECT>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
                                                  walk_flags & (1 | 64), 0u, c->heur_slot, 0x7fffffff, D.prev_paths + ((int64_t)slot * D.max_colony + a) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
 #ifdef WA_STRAG_TIME
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     int32_t cut_n = 0x7fffffff;
     if (!SPARSE && ALPHA1 && (walk_flags & 32) && D.pool_n) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
     if (cut_n < 1) cut_n = 1;
-    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
+    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ, DIRECT>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot, cut_n, nullptr, 0, gen);
 #ifdef WA_STRAG_TIME
     if (threadIdx.x == 0 && gen < 128) {

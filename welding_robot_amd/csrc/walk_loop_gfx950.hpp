@@ -54,6 +54,27 @@
 #define WA_ASM_WARM1_NONE "s_nop 0\n"
 #define WA_ASM_VMWAIT_NONE "s_waitcnt vmcnt(2)\n"
 #define WA_ASM_VMWAIT_LAZY_NONE "s_waitcnt vmcnt(3)\n"
+// W = DIRECT (round 5): NO look-ahead.  The step after the pick requests only the records of the voxel the ant has just moved to
+// (one 24-byte record per field instead of six: 2-4 cache lines named per step instead of 12-14) and the next step waits for them.
+// What a saturated launch pays for the look-ahead is memory-system load (profiles/r04/pmc_walk_p8.txt: 4.3 L1->L2 requests and ~2 L2
+// misses per step for the two records a step uses); what DIRECT pays is the load's latency on every step's chain, which the other
+// resident wavefronts of a saturated launch are there to cover.  Same lanes, same arithmetic: every lane block requests the record of
+// `cur` itself (lane constant dj = 0, see wa_walk_fast_asm), the active block is always block 0.
+#define WA_ASM_WARM_ADDR_DIRECT ""
+#define WA_ASM_WARM0_DIRECT "s_nop 0\n"
+#define WA_ASM_WARM1_DIRECT "s_nop 0\n"
+#define WA_ASM_VMWAIT_DIRECT "s_waitcnt vmcnt(0)\n"
+#define WA_ASM_VMWAIT_LAZY_DIRECT "s_waitcnt vmcnt(0)\n"
+// where the step's tail puts the records it requests: look-ahead -> where THIS step's records were (needed by the step after the next
+// one); DIRECT -> the other register set (needed by the NEXT step), loads in front of the probe (they are what the next step waits for)
+#define WA_ASM_REQ_SELF(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT(CP, CH, CS, HEAD)
+#define WA_ASM_REQ_NONE(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT(CP, CH, CS, HEAD)
+#define WA_ASM_REQ_DIRECT(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT_LOADS(NP, NH, NS, HEAD) WA_SPAN_8 WA_ASM_NEXT_PROBE
+// the block that holds the next step's records: the picked lane's position -- or, DIRECT, block 0 for ever (s[54:55] stays 63 << 0
+// until an event zeroes it; the event handler restores it from %[g8] = 0)
+#define WA_ASM_ACTIVE_SELF "s_lshl_b32 %[g8], s45, 3\n" "s_lshl_b64 s[54:55], 63, %[g8]\n"
+#define WA_ASM_ACTIVE_NONE WA_ASM_ACTIVE_SELF
+#define WA_ASM_ACTIVE_DIRECT ""
 // -DWA_ASM_STAMPS (diagnostic builds, tools/walk_stamps_asm.py): s_memtime at six points of the step, differences summed in
 // s72..s77 (s70 = previous stamp); each stamp drains LDS and costs ~40 cycles: read the shares, not the totals
 // -DWA_ASM_SPAN_A=a -DWA_ASM_SPAN_B=b (diagnostic builds, tools/walk_spans.py): ONE pair of s_memtime per step, at points a and b of
@@ -350,10 +371,9 @@
     "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
     "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
     WA_SPAN_7                                                                                                     \
-    "s_lshl_b32 %[g8], s45, 3\n"                                  /* next active block = position of the pick (low 6 bits count) */ \
-    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
+    WA_ASM_ACTIVE_##W                                             /* next active block = position of the pick (low 6 bits count) */ \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
-    WA_ASM_NEXT(CP, CH, CS, HEAD)                                                                                 \
+    WA_ASM_REQ_##W(CP, CH, CS, NP, NH, NS, HEAD)                                                                 \
     WA_SPAN_9                                                                                                     \
     "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
     "s_add_i32 m0, m0, 1\n"                                                                                       \
@@ -752,7 +772,8 @@ __device__ __forceinline__ void wa_glibc_seek(const int32_t *snap, int32_t k, in
 // hands back at every block boundary (code 0, the block stored), the next 64 draws are generated here and it re-enters (its prologue
 // re-requests the records: ~1 us per 64 steps).  A dead end is handed to the caller's generic loop undecided: the reference only calls
 // rand() when a candidate exists (:162-166), and the loop's single exit does not say which of the two dead ends it met.
-template <int VARIANT, bool WARM = true, bool REFDRAW = false>
+// DIRECT: no look-ahead (W = DIRECT above): every lane block requests the record of `cur` itself, the active block is always block 0
+template <int VARIANT, bool WARM = true, bool REFDRAW = false, bool DIRECT = false>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
                                                  int32_t *path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
@@ -771,7 +792,8 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const int k2 = pos < 6 ? 5 - pos : 0;   // edge this lane evaluates; positions 6,7 of a group are padding (never admissible)
     // lane block b = lane >> 3 fetches the record of neighbour 5 - b: the block that becomes active after a move is
     // then the POSITION of the picked lane (edge k sits at position 5 - k), one s_lshl away from the pick
-    const int32_t dk = wa_delta(k2, nx, nxy), dj = wa_delta(j < 6 ? 5 - j : 5, nx, nxy);
+    const int32_t dk = wa_delta(k2, nx, nxy), dj = DIRECT ? 0 : wa_delta(j < 6 ? 5 - j : 5, nx, nxy);
+    static_assert(!(DIRECT && WARM), "the touch loads belong to the look-ahead");
     const int32_t limit_full = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
     int32_t limit = limit_full;   // (REFDRAW: the end of the current block, see below)
     const int32_t table = 1 << hash_log2;
@@ -833,13 +855,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         if (REFDRAW) limit = (len | 63) + 1;
         int32_t code;
         if (REJOIN && !LAZY) {
-            if (WARM) { WA_ASM_RUN_REJ(SELF) } else { WA_ASM_RUN_REJ(NONE) }
+            if (DIRECT) { WA_ASM_RUN_REJ(DIRECT) } else if (WARM) { WA_ASM_RUN_REJ(SELF) } else { WA_ASM_RUN_REJ(NONE) }
         } else if (!LAZY) {
-            if (WARM) { WA_ASM_RUN_DENSE(SELF) } else { WA_ASM_RUN_DENSE(NONE) }
+            if (DIRECT) { WA_ASM_RUN_DENSE(DIRECT) } else if (WARM) { WA_ASM_RUN_DENSE(SELF) } else { WA_ASM_RUN_DENSE(NONE) }
         } else if (REJOIN) {
-            if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, SELF, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
+            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, DIRECT, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
+            else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, SELF, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
         } else {
-            if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, SELF, "", "") } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "") }
+            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, DIRECT, "", "") } else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, SELF, "", "") } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "") }
         }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {

@@ -81,6 +81,7 @@ struct wa_acs {
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     int walk_warm;         // touch loads in the hand-scheduled loop: -1 by launch size (wa_acs_run), 0 / 1 forced (WA_WALK_WARM)
+    int walk_direct;       // the loop WITHOUT look-ahead for saturated launches: -1 by rule (walk_direct_rule), 0 / 1 forced (WA_WALK_DIRECT)
     int walk_flags;        // k_walk_dev's switches: hand-scheduled loop, re-entry onto the replay track (WA_REENTRY=0: off), see acs_create
     WaRun R;
     bool begun;
