@@ -55,7 +55,9 @@ int main(int argc, char **argv)
     if (!model.readFile(argv[1])) return 1;
     const std::vector<Triangles<float>> meshes = model.TriangleList();
     SearchPath.creatGridMap(meshes, strtof(argv[2], NULL), atoi(argv[3]), "");
-    if (SearchPath.lastStatus() != WA_OK) { printf("%s\n", wa_last_error(weldacs_dropin::context())); return 3; }
+    // (gridStatus() is GridMap's verdict on creatGridMap; lastStatus() is ACS_Rank's own, about the searches -- found by the sanitizer
+    //  leg, tests/test_sanitizers.py: without a device the wrong one let the program run on into a null grid)
+    if (SearchPath.gridStatus() != WA_OK || !SearchPath.ptr_grid_map()) { printf("grid map: status %d\n", SearchPath.gridStatus()); return 3; }
 
     // ---- a polyline of 400 control points through the grid's bounding box, as main.cpp hands the stitched path to BS_Basic<float,3,0,0,0>
     const int pt_num = 400;

@@ -51,14 +51,22 @@ int wa_device_count(void);
 /* free / total memory of the context's device in bytes (either pointer may be NULL): what the slot count of a solver for many
  * pair searches is sized by, and what a caller can poll after another process has just released the GPU */
 int wa_ctx_memory_info(wa_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
-/* A context keeps the device blocks (1 MiB and up) of the solvers destroyed on it and hands them to the next solver it creates: the
- * reference never frees anything (SURVEY 8(b) ownership) and creates its search once per process; a host that runs
- * searchBestPathOfPoints per job would otherwise pay the driver's wipe of the freed memory before every re-allocation (seconds for
- * a C5-sized solver).  Kept bytes count as free in wa_ctx_memory_info and go back to the driver when the device runs out, on
- * wa_ctx_trim and with the context.  Other PROCESSES on the same GPU cannot have those bytes until then: a host that shares its GPU
- * trims after its last job.  WA_DEV_CACHE=0 in the environment switches the mechanism off. */
+/* A context keeps the device memory (blocks of 1 MiB and up) of the solvers destroyed on it and builds the next solver from it: the
+ * reference never frees anything (SURVEY 8(b) ownership; ACSRank_3D.hpp:456-460 allocates once) and creates its search once per
+ * process; a host that runs searchBestPathOfPoints per job would otherwise pay the driver's wipe of the freed memory before every
+ * re-allocation (seconds for a C5-sized solver).  Where the device supports virtual memory management the memory is kept as an ARENA
+ * of physical chunks (512 MiB and 32 MiB) that are mapped into a fresh address range for every block of 32 MiB and up, so a solver of
+ * ANY shape is served from what solvers of other shapes gave back; smaller blocks, and every block without that support
+ * (WA_DEV_ARENA=0), are whole allocations reused for requests of nearly their size.  Kept bytes count as free in wa_ctx_memory_info;
+ * at most WA_DEV_KEEP_PCT (95) percent of the device's memory is kept; when the device runs out, kept memory goes back to the driver
+ * -- as much as is needed --, as it does on wa_ctx_trim and with the context.  Other PROCESSES on the same GPU cannot have those bytes
+ * until then: a host that shares its GPU trims after its last job.  WA_DEV_CACHE=0 in the environment switches the mechanism off. */
 int wa_ctx_cached_bytes(wa_ctx *ctx, int64_t *bytes);
 int wa_ctx_trim(wa_ctx *ctx);
+/* counters since the context was created: [0] blocks asked for (1 MiB and up), [1] bytes served from kept memory, [2] bytes newly
+ * obtained from the driver, [3] bytes given back to the driver, [4] blocks served ENTIRELY from kept memory, [5] out-of-memory events
+ * handled by releasing kept memory, [6] milliseconds spent building arena blocks, [7] 1 when the arena is in use */
+int wa_ctx_cache_stats(wa_ctx *ctx, int64_t out[8]);
 /* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling
  * thread's current HIP device, and restores the caller's current device before returning. */
 int wa_ctx_create(int device_ordinal, wa_ctx **out);

@@ -176,7 +176,9 @@ def test_c5_full_size_pair_planning_and_seam_order(ctx):
     assert sorted(order) == list(range(P))
     # the context keeps the blocks of the solvers destroyed above for its next solver (wa_ctx_cached_bytes); the tests below start OTHER
     # processes on this GPU, which would wait for that memory (bench.py: wait_for_device_memory)
-    assert ctx.cached_bytes() > (50 << 30)
+    # (round 5: the arena builds every solver from the same chunks, so what is kept is the largest footprint -- the 48-slot solver's ~41 GB
+    #  -- not the sum of every shape's blocks as with round 4's exact-fit cache)
+    assert ctx.cached_bytes() > (30 << 30)
     ctx.trim()
     assert ctx.cached_bytes() == 0
 

@@ -35,6 +35,7 @@ SYMBOLS = {
     "wa_ctx_memory_info": (C.c_int, [_V, _P, _P]),
     "wa_ctx_cached_bytes": (C.c_int, [_V, _P]),
     "wa_ctx_trim": (C.c_int, [_V]),
+    "wa_ctx_cache_stats": (C.c_int, [_V, _P]),
     "wa_ctx_create": (C.c_int, [C.c_int, C.POINTER(_V)]),
     "wa_ctx_destroy": (None, [_V]),
     "wa_last_error": (C.c_char_p, [_V]),

@@ -80,6 +80,15 @@ class Context:
         """give the kept blocks back to the driver (wa_ctx_trim)"""
         self.check(self.lib.wa_ctx_trim(self.h))
 
+    def cache_stats(self):
+        """wa_ctx_cache_stats as a dict: what the context's kept memory served and what had to come from the driver"""
+        v = (C.c_int64 * 8)()
+        self.check(self.lib.wa_ctx_cache_stats(self.h, v))
+        keys = ("blocks", "hit_bytes", "miss_bytes", "released_bytes", "blocks_all_from_kept", "oom_events", "arena_build_ms", "arena")
+        d = {k: int(x) for k, x in zip(keys, v)}
+        d["kept_bytes"] = self.cached_bytes()
+        return d
+
     def sync(self):
         self.check(self.lib.wa_ctx_sync(self.h))
 

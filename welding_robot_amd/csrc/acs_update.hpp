@@ -627,6 +627,12 @@ __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0,
         stamp[id] = 0;
     }
 }
+// rows of `width` words, `pitch` words apart -> packed (wa_acs_result_batch: the best paths of all slots in one host copy).  grid.y = rows.
+__global__ __launch_bounds__(256) void k_gather_rows(int32_t *__restrict__ dst, const int32_t *__restrict__ src, int64_t pitch, int64_t width)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) dst[(int64_t)blockIdx.y * width + i] = src[(int64_t)blockIdx.y * pitch + i];
+}
 // The two init modes (initFromGridMap: out-of-bounds edges 0, ACSRank_3D.hpp:389-403; reset(): every edge pheromone_0, :307-315) differ
 // ONLY in the out-of-bounds edges, and those exist on the six faces of the lattice only: a lazy slot that changes mode with p0 unchanged
 // (the first reset() behind initFromGridMap -- every pair-planning run) rewrites 2(nx ny + nx nz + ny nz) floats instead of 6 N
