@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--cost-check-gens", type=int, default=None, help="generations the CPU port replays for cost_check (default: all K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-every", type=int, default=10, help="stamp every n-th generation's launches with HIP events")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary C5-shaped pair-planning measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="warm-up + timed region only: no continuation of the search behind the timed region (roofline samples), no walk_step, no secondary measurements "
+                         "-- what a rocprofv3 kernel trace of the command should contain (tools/timed_window_stats.py)")
     ap.add_argument("--no-roofline-256", action="store_true", help="skip the 256^3 (past the Infinity Cache) sweep measurement")
     ap.add_argument("--workload-index", type=int, default=None,
                     help="run rank R's C4 workload (grid seed 2024+R, colony seed 12345+R) on this GPU; default = own rank")
@@ -379,20 +381,116 @@ def c5_full_extra(ctx):
     pts = synth.synth_weld_points(free, n, P, seed=seed)
     t_inputs = time.perf_counter() - t0
     predict = float(24 / 0.35)
-    waited = pb.wait_for_device_memory(ctx)   # (solvers of the earlier extras may still be giving their memory back, see examples/plan_batch.py)
-    t0 = time.perf_counter()
-    cost, paths, mine = pb.plan(ctx, grid, pts, gens, predict, seed, 0, lazy=True)
-    ctx.sync()
-    t_pairs = time.perf_counter() - t0 - pb.plan.last_create_s
+    waited = pb.wait_for_device_memory(ctx)   # (a process that has just exited may still be giving its memory back, see examples/plan_batch.py)
+    GiB = float(1 << 30)
+    runs = []
+    for rep in range(2):
+        # first: the solver is built from what the context kept of the earlier extras' solvers (other shapes: the arena re-maps their chunks)
+        # plus fresh memory, which the driver zero-fills when it is allocated (~25-40 ms per GB: that, not the library, is the first creation);
+        # second: the same job again, as a planning service (or the drop-in, which creates its solver per searchBestPathOfPoints call) pays it
+        st0 = ctx.cache_stats()
+        t0 = time.perf_counter()
+        cost, paths, mine = pb.plan(ctx, grid, pts, gens, predict, seed, 0, lazy=True)
+        ctx.sync()
+        t_pairs = time.perf_counter() - t0 - pb.plan.last_create_s
+        st1 = ctx.cache_stats()
+        runs.append({"t_solver_create_s": pb.plan.last_create_s, "t_pairs_s": t_pairs, "slots": pb.plan.last_slots,
+                     "cache_hit_gib": (st1["hit_bytes"] - st0["hit_bytes"]) / GiB, "cache_miss_gib": (st1["miss_bytes"] - st0["miss_bytes"]) / GiB,
+                     "released_to_driver_gib": (st1["released_bytes"] - st0["released_bytes"]) / GiB, "out_of_memory_events": st1["oom_events"] - st0["oom_events"],
+                     "kept_gib_after": st1["kept_bytes"] / GiB})
+        if rep == 0:
+            first_cost = cost
+    same = bool(np.array_equal(first_cost, cost))
     t0 = time.perf_counter()
     tour = api.gtsp_solve(ctx, cost, mode=api.RNG_DEV, seed=seed)
     t_gtsp = time.perf_counter() - t0
     grid.close()
     pairs = P * (P - 1) // 2
+    warm = runs[1]
     return {"workload": "256^3 grid, 64 weld points = %d pair searches x %d generations, 24 ants, lazy evaporation; then the 64-seam order" % (pairs, gens),
-            "slots_by_rule": pb.plan.last_slots, "batches": -(-pairs // pb.plan.last_slots), "t_pairs_s": t_pairs, "t_solver_create_s": pb.plan.last_create_s,
-            "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "t_memory_wait_s": waited, "pair_generations_per_s": pairs * gens / t_pairs,
+            "slots_by_rule": warm["slots"], "batches": -(-pairs // warm["slots"]), "t_pairs_s": warm["t_pairs_s"], "t_solver_create_s": warm["t_solver_create_s"],
+            "t_pairs_first_s": runs[0]["t_pairs_s"], "t_solver_create_first_s": runs[0]["t_solver_create_s"],
+            "cache": {"arena": bool(ctx.cache_stats()["arena"]), "first": runs[0], "second": runs[1],
+                      "note": "t_solver_create_s / t_pairs_s: the job run a second time on the same context (every block served from kept memory); *_first_s: the first "
+                              "time, behind the other extras' solvers -- cache_miss_gib of it is fresh device memory, which the driver zero-fills at allocation"},
+            "identical_costs_both_times": same,
+            "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "t_memory_wait_s": waited, "pair_generations_per_s": pairs * gens / warm["t_pairs_s"],
             "all_reached": bool(np.isfinite(cost).all()), "tour_cost": float(tour["L"][0]), "tour_iterations": int(tour["iters"][0])}
+
+
+def c5_sharded_extra(ctx, comm, rank, world, check_against_one_rank=True):
+    """BASELINE config 5 as the multi-GPU job it is (N > 1, or WA_FORCE_DIST=1): STRONG scaling -- the 2 016 pair searches of ONE planning job
+    dealt over the ranks.  Rank 0 builds the 256^3 grid and wa_comm_broadcast_grid ships it (occupancy + axis tables: ncclBroadcast, SURVEY 8(e));
+    the pairs are dealt longest-processing-time-first in end-point groups (the drop-in's rule: welding_robot_amd/dist.py = ACSRank_3D.hpp drop-in
+    `deal`); every rank plans its share (lazy evaporation, slots by rule); wa_comm_allgather_costs brings every cost to every rank and
+    wa_comm_gather_paths every path to rank 0, which orders the seams (ACS_GTSP.hpp:224-253, :286-298 need the whole matrix on one rank).
+    Reported: aggregate pair-generations/s over the slowest rank's wall time incl. the exchanges, the per-rank search times and their
+    imbalance, the exchange times; checked: cost matrix and tour equal the ONE-rank run of the same job (rank 0 repeats it alone).
+    WA_BENCH_C5="grid,points,generations" shrinks the job (tests: several ranks on one GPU).  Outside `value`."""
+    import importlib.util
+    import numpy as np
+    from welding_robot_amd import api, synth
+    from welding_robot_amd import dist as wd
+    spec = importlib.util.spec_from_file_location("plan_batch", os.path.join(ROOT, "examples", "plan_batch.py"))
+    pb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pb)
+    n, P, gens = (int(v) for v in os.environ.get("WA_BENCH_C5", "256,64,150").split(","))
+    slots = int(os.environ.get("WA_BENCH_C5_SLOTS", "0"))
+    seed, predict = 7, float(24 / 0.35)
+    free = None
+    t0 = time.perf_counter()
+    if rank == 0:
+        free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+        mine_grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    else:
+        mine_grid = None
+    comm.barrier()
+    t1 = time.perf_counter()
+    grid = comm.broadcast_grid(mine_grid, root=0)
+    t_bcast = time.perf_counter() - t1
+    if free is None:
+        free = grid.occupancy()                       # (the weld points are drawn from the grid every rank now holds)
+    pts = synth.synth_weld_points(free, n, P, seed=seed)
+    pair_list = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    comm.barrier()
+    t2 = time.perf_counter()
+    cost, paths, n_mine = pb.plan(ctx, grid, pts, gens, predict, seed, slots, rank, world, lazy=True)
+    ctx.sync()
+    t_search = time.perf_counter() - t2 - pb.plan.last_create_s
+    t3 = time.perf_counter()
+    index_of = {ij: k for k, ij in enumerate(pair_list)}
+    mine = sorted(index_of[ij] for ij in paths)
+    vec = comm.allgather_costs(mine, [cost[pair_list[k]] for k in mine], len(pair_list))
+    full = np.zeros((P, P), np.float64)
+    for k, (i, j) in enumerate(pair_list):
+        full[i, j] = full[j, i] = vec[k]
+    gathered = comm.gather_paths({k: paths[pair_list[k]] for k in mine}, root=0)
+    t_exchange = time.perf_counter() - t3
+    t_job = time.perf_counter() - t2 - pb.plan.last_create_s       # search + exchange on this rank (solver creation: a one-off, reported beside it)
+    t_all = comm.allreduce([t_search, t_job, t_exchange, pb.plan.last_create_s], "max")
+    t_sum = comm.allreduce([t_search, float(n_mine)], "sum")
+    t_min = comm.allreduce([t_search], "min")
+    out = None
+    if rank == 0:
+        tour = api.gtsp_solve(ctx, full, mode=api.RNG_DEV, seed=seed)
+        pairs = len(pair_list)
+        out = {"workload": "%d^3 grid, %d weld points = %d pair searches x %d generations dealt over %d rank(s), lazy evaporation; then the seam order on rank 0"
+                           % (n, P, pairs, gens, world),
+               "scaling": "strong", "ranks": world, "pairs": pairs, "pairs_per_rank_mean": t_sum[1] / world, "slots_rank0": pb.plan.last_slots,
+               "pair_generations_per_s": pairs * gens / t_all[1], "t_job_s_slowest_rank": t_all[1],
+               "t_search_s": {"slowest": t_all[0], "fastest": t_min[0], "mean": t_sum[0] / world, "imbalance_max_over_mean": t_all[0] / (t_sum[0] / world)},
+               "t_exchange_s_slowest_rank": t_all[2], "t_grid_broadcast_s": t_bcast, "grid_broadcast_bytes": int(n) ** 3 + 12 * n,
+               "t_solver_create_s_slowest_rank": t_all[3], "paths_on_rank0": len(gathered), "all_reached": bool(np.isfinite(full).all()),
+               "tour_cost": float(tour["L"][0]), "tour_iterations": int(tour["iters"][0])}
+        if check_against_one_rank:
+            c1, p1, _ = pb.plan(ctx, grid, pts, gens, predict, seed, slots, 0, 1, lazy=True)
+            t1r = api.gtsp_solve(ctx, c1, mode=api.RNG_DEV, seed=seed)
+            out["equals_one_rank_run"] = bool(np.array_equal(c1, full) and np.array_equal(t1r["edges"][0], tour["edges"][0]) and
+                                              all(np.array_equal(p1[pair_list[k]], gathered[k]) for k in gathered) and len(gathered) == pairs)
+            assert out["equals_one_rank_run"], "the sharded C5 run differs from the one-rank run"
+    comm.barrier()
+    grid.close()
+    return out
 
 
 def pair_planning_extra(ctx, grid, free, n):
@@ -571,7 +669,7 @@ def main():
         # blocks + the rank / mark blocks), per-dispatch HIP events on the library's stream over the timed region
         fused = dict(prof["evaporate"])
         fused_where = "%d launches of the timed region" % fused["launches"]
-        if fused["launches"] < 32:   # a short timed region: the same search goes on, untimed, every launch stamped, until 32 samples exist
+        if fused["launches"] < 32 and not args.no_extras:   # a short timed region: the same search goes on, untimed, every launch stamped, until 32 samples exist
             solver.profile(True, 1)
             solver.run(32 - int(fused["launches"]))
             more = solver.profile_read()["evaporate"]
@@ -637,9 +735,8 @@ def main():
             "steps_per_generation_first_last": [int(trace["steps"][0]), int(trace["steps"][-1])],
             "device": ctx.device_name,
         }
-        if world == 1:
-            out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
         if world == 1 and not args.no_extras:
+            out["walk_step"] = walk_step_extra(solver, params(K, wl["rng_seed"]), ids, wl)
             out["full_run"] = full_run_extra(solver, params, ids, wl, n)
             out["ref_mode"] = ref_mode_extra(solver, ids, n, args.ants)
             out["multi_start"] = multi_start_extra(ctx, grid, params, ids, n, args.ants)
@@ -647,6 +744,15 @@ def main():
             out["c5_pair_planning"] = pair_planning_extra(ctx, grid, free, n)
             solver.close()
             out["c5_full"] = c5_full_extra(ctx)
+    c5s = None
+    if comm is not None and (not args.no_extras or os.environ.get("WA_BENCH_C5")):
+        # every rank takes part (rank 0 reports): BASELINE config 5 as ONE job over the ranks -- the leg where N GPUs shorten a job (strong
+        # scaling); the headline above is C4, one independent search per GPU (weak)
+        solver.close() if world > 1 else None
+        c5s = c5_sharded_extra(ctx, comm, rank, world)
+    if rank == 0:
+        if c5s is not None:
+            out["c5_sharded"] = c5s
         if world == 1 and not args.no_cpu:
             # the CPU leg comes last (the extras before it are host-paced: 0.52-0.84 s for the C5 extra from box to box, whatever runs in front)
             out.update(cpu_baseline(args, free, n, trace, wl, path, K, elapsed * 1e3))

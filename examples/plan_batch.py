@@ -10,7 +10,7 @@ the tour's segments stitched and smoothed on the device (main.cpp:283-352).
 
 Every pair uses its GLOBAL pair index as DEV-mode stream key, so the cost matrix -- and the tour --
 do not depend on the number of ranks or slots.  One process per GPU; the exchanges at the end are the library's own
-(RCCL behind the C ABI, no torch): wa_comm_allgather_costs brings every pair's cost to every rank (8 KB at P = 64) and
+(RCCL behind the C ABI, no torch): wa_comm_broadcast_grid ships rank 0's grid to the others, wa_comm_allgather_costs brings every pair's cost to every rank (8 KB at P = 64) and
 wa_comm_gather_paths every pair's path to rank 0, which orders the seams and stitches (ACS_GTSP.hpp:286-298 needs all of
 best_matrix on one rank).  WA_FORCE_DIST=1 runs the same exchanges with the one rank a 1-GPU box has.
 """
@@ -100,8 +100,17 @@ def main():
         comm.barrier()
     wait_for_device_memory(ctx)
     n = args.grid
-    free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
-    grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    if comm is None or rank == 0:
+        free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+        grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+    else:
+        grid = None
+    if comm is not None:
+        # ONE rank builds the grid (with a mesh that is the O(triangles x voxels) voxelisation, model_grid_map.hpp:223-268), the others
+        # receive a replica: occupancy + axis tables by ncclBroadcast (wa_comm_broadcast_grid)
+        grid = comm.broadcast_grid(grid, root=0)
+        if rank != 0:
+            free = grid.occupancy()
     pts = synth.synth_weld_points(free, n, args.points, seed=args.seed)
     predict = float(0.35 ** -1 * 24)  # 24 ants per search at precision 1 (ACSRank_3D.hpp:247)
     t0 = time.perf_counter()

@@ -300,6 +300,15 @@ int wa_comm_allgather_costs(wa_comm *c, int32_t n_mine, const int32_t *index_min
 int wa_comm_gather_paths(wa_comm *c, int32_t root, int32_t n_mine, const int32_t *index_mine, const int64_t *len_mine, const int32_t *ids_mine,
                          int64_t *n_paths_total, int64_t *n_ids_total);
 int wa_comm_gathered_paths_read(wa_comm *c, int32_t *index_out, int64_t *len_out, int32_t *ids_out);
+/* paths / node ids the last wa_comm_gather_paths left on this rank (the root: every rank's; elsewhere 0): what the three buffers of
+ * wa_comm_gathered_paths_read must hold.  A gather that failed leaves nothing readable (0, 0). */
+int wa_comm_gathered_paths_counts(const wa_comm *c, int64_t *n_paths, int64_t *n_ids);
+/* The occupancy grid to every rank, once: rank `root` built its grid -- wa_grid_from_mesh is the reference's O(triangles x
+ * voxels) creatGridMap, model_grid_map.hpp:223-268 -- and every other rank receives a replica (occupancy + the three axis tables:
+ * ncclBroadcast over xGMI; 16 MiB at 256^3) instead of repeating that step.  `grid`: the root's grid (ignored elsewhere).  *out: a new
+ * grid owned by the caller on every rank but the root, NULL on the root (which keeps using its own).  Collective: every rank calls it;
+ * a rank whose arguments are bad still takes part in the header exchange, so that all ranks return an error together. */
+int wa_comm_broadcast_grid(wa_comm *c, int32_t root, const wa_grid *grid, wa_grid **out);
 /* bookkeeping helpers for a C++ launcher (timing max over ranks, totals): blocking all-reduce of host doubles */
 enum { WA_COMM_MIN = 0, WA_COMM_MAX = 1, WA_COMM_SUM = 2 };
 int wa_comm_allreduce_f64(wa_comm *c, double *inout, int32_t count, int32_t op);

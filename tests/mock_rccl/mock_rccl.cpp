@@ -1,4 +1,4 @@
-// mock_rccl.cpp -- TEST INFRASTRUCTURE, not part of the product: a stand-in for the eleven RCCL entry points libweldacs.so calls
+// mock_rccl.cpp -- TEST INFRASTRUCTURE, not part of the product: a stand-in for the twelve RCCL entry points libweldacs.so calls
 // (csrc/host_comm.inc), so that the multi-rank paths of wa_comm_* can be run with world > 1 on a box that has ONE GPU -- RCCL itself
 // refuses two ranks on one device.  LD_PRELOADed in front of librccl by tests/test_gpu_mock_ranks.py; ranks are processes or threads
 // that share the GPU and exchange through files in a directory named by the unique id (MOCK_RCCL_DIR, default /tmp/mock_rccl_<uid>).
@@ -198,6 +198,23 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t sendcount, ncclD
     std::vector<uint8_t> mine, all;
     if (!to_host(send, mine, bytes, st) || !exchange(c, mine.data(), bytes, all)) return ncclSystemError;
     return to_dev(recv, all.data(), all.size()) ? ncclSuccess : ncclSystemError;
+}
+
+ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataType_t t, int root, ncclComm_t c, hipStream_t st)
+{
+    const size_t bytes = type_bytes(t) * count;
+    if (!c || !type_bytes(t) || root < 0 || root >= c->nranks) return ncclInvalidArgument;
+    char name[64];
+    snprintf(name, sizeof name, "/b%ld.r%d", c->coll_seq++, root);
+    if (c->rank == root) {
+        std::vector<uint8_t> mine;
+        if (!to_host(send, mine, bytes, st) || !put_file(c->dir + name, mine.data(), bytes)) return ncclSystemError;
+        if (recv != send && !to_dev(recv, mine.data(), bytes)) return ncclSystemError;
+        return ncclSuccess;
+    }
+    std::vector<uint8_t> got(bytes);
+    if (hipStreamSynchronize(st) != hipSuccess || !get_file(c->dir + name, got.data(), bytes)) return ncclSystemError;
+    return to_dev(recv, got.data(), bytes) ? ncclSuccess : ncclSystemError;
 }
 
 ncclResult_t ncclSend(const void *send, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st)

@@ -57,13 +57,42 @@ def main():
         for i in range(rank + 2):
             paths[1000 * rank + i] = np.arange(7 * rank + i, 7 * rank + i + (0 if i == 1 else 5 + 3 * i), dtype=np.int32)
     got = comm.gather_paths(paths, root=root)
+    # ---- (5) the occupancy grid from a root that is NOT rank 0: the root voxelises the mesh on the device (wa_grid_from_mesh), the others
+    #      receive a replica (wa_comm_broadcast_grid) and resolve a point on it
+    from welding_robot_amd._lib import WeldacsError
+    broot = 1 % world
+    stl = os.path.join(ROOT, "tests", "golden", "cubic.stl")
+    mine_grid = api.Grid.from_mesh(ctx, api.stl_read_file(stl), 0.0219, 8) if rank == broot else None
+    bg = comm.broadcast_grid(mine_grid, root=broot)
+    b_occ, (b_cx, b_cy, b_cz) = bg.occupancy(), bg.coords()
+    b_meta = np.array([bg.nx, bg.ny, bg.nz, bg.wall, bg.n_free, int(np.float32(bg.precision).view(np.uint32))], np.int64)
+    b_ids = bg.resolve(np.array([[b_cx[4], b_cy[4], b_cz[4]], [b_cx[20], b_cy[27], b_cz[20]]], np.float32))
+    # ---- (6) a rank with bad arguments does not leave the others hanging: every rank gets an error from the same call
+    errs = []
+    try:
+        comm.allgather_costs([n_total + 5] if rank == world - 1 else [0], [1.0], n_total, fill=0.0)   # the last rank's index is out of range
+        errs.append(0)
+    except WeldacsError:
+        errs.append(1)
+    try:
+        comm.gather_paths({3: np.arange(4, dtype=np.int32)}, root=(world + 7) if rank == 0 else 0)   # rank 0 names a root that does not exist
+        errs.append(0)
+    except WeldacsError:
+        errs.append(1)
+    try:
+        comm.broadcast_grid(None, root=0)                                                            # the root has no grid to send
+        errs.append(0)
+    except WeldacsError:
+        errs.append(1)
+    after = comm.allreduce([float(rank)], "sum")                                                     # ... and the communicator still works
     comm.barrier()
     np.savez(out + ".rank%d.npz" % rank, cost=cost, owner_rank=owner_rank, owner_slot=owner_slot, mine=mine,
              red_min=red["min"], red_max=red["max"], red_sum=red["sum"], vec=vec,
              got_keys=np.array(sorted(got), np.int64), got_ids=np.concatenate([got[k] for k in sorted(got)] + [np.zeros(0, np.int32)]),
              got_lens=np.array([len(got[k]) for k in sorted(got)], np.int64),
              sent_keys=np.array(sorted(paths), np.int64), sent_ids=np.concatenate([paths[k] for k in sorted(paths)] + [np.zeros(0, np.int32)]),
-             sent_lens=np.array([len(paths[k]) for k in sorted(paths)], np.int64))
+             sent_lens=np.array([len(paths[k]) for k in sorted(paths)], np.int64),
+             b_occ=b_occ, b_cx=b_cx, b_cy=b_cy, b_cz=b_cz, b_meta=b_meta, b_ids=b_ids, errs=np.array(errs), after=after)
     comm.close()
     s.close()
     dg.close()

@@ -55,7 +55,7 @@ def test_the_mock_stands_in_for_every_rccl_entry_point_the_library_calls():
         assert r.returncode == 0, r.stderr
         return {l.split()[-1] for l in r.stdout.splitlines() if (" %s nccl" % kind) in l}
     wanted, have = syms(_lib.LIB_PATH, "U"), syms(mock, "T")
-    assert len(wanted) >= 11 and wanted <= have, wanted - have
+    assert len(wanted) >= 12 and wanted <= have, wanted - have
 
 
 @pytest.mark.gpu
@@ -143,6 +143,25 @@ def test_costs_and_paths_of_a_sharded_pair_run_reach_the_stitching_rank():
     assert set(got) == set(paths) and all(np.array_equal(got[k], paths[k]) for k in paths)
     assert comm.gather_paths({}, root=0) == {}
     comm.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_grid_broadcast_with_one_rank_issues_the_collective_and_keeps_the_roots_grid():
+    """wa_comm_broadcast_grid with the world a 1-GPU box can form: the header all-gather and the four ncclBroadcast calls are really issued
+    (RCCL, in place), the root gets no replica (it keeps its own grid), bad arguments fail instead of hanging.  World > 1: the mock-ranks test."""
+    ctx = api.Context(0)
+    comm = api.Comm(ctx, 0, 1, api.Comm.unique_id())
+    og = O.synth_grid(24, seed=5, occ_prob=0.2)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    before = dg.occupancy().copy()
+    bg = comm.broadcast_grid(dg, root=0)
+    assert bg is dg and np.array_equal(dg.occupancy(), before) and dg.n_free == int(og.free.sum())
+    with pytest.raises(api.WeldacsError):
+        comm.broadcast_grid(None, root=0)
+    with pytest.raises(api.WeldacsError):
+        comm.broadcast_grid(dg, root=3)
+    assert comm.allreduce([2.5], "sum").tolist() == [2.5]      # the communicator still works
+    comm.close(); dg.close(); ctx.close()
 
 
 def test_best_key_packs_cost_and_owner_in_one_orderable_word():

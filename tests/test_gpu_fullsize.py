@@ -211,6 +211,16 @@ def test_c4_rccl_path_with_one_rank(path):
     assert d["best_cost"] == d["best_cost_all_ranks"] and np.isfinite(d["best_cost"]) and d["value"] > 0
 
 
+def test_c5_sharded_leg_with_one_rank_over_real_rccl():
+    """bench.py's C5 strong-scaling leg (`c5_sharded`) with the one rank RCCL itself admits on a 1-GPU box: the grid broadcast, the cost all-gather
+    and the path gather are ISSUED through librccl (no stand-in), and the result equals the plain one-rank plan.  (Several ranks: the mock-ranks test.)"""
+    port = 29500 + (os.getpid() + 17) % 2000
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "2", "--no-cpu", "--no-extras"], env={"WA_FORCE_DIST": "1", "WA_BENCH_C5": "96,16,80"},
+               launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
+    c5 = d["c5_sharded"]
+    assert c5["ranks"] == 1 and c5["pairs"] == 120 and c5["paths_on_rank0"] == 120 and c5["equals_one_rank_run"] is True and c5["all_reached"]
+
+
 def test_c4_workload_of_rank_7_on_this_gpu():
     """Rank 7's C4 problem (grid seed 2031, colony seed 12352) run here: the DEV-mode port draws the same numbers, so the
     per-generation best-cost trace must be bit-equal to the CPU's."""

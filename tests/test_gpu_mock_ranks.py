@@ -1,5 +1,5 @@
 """The multi-rank paths of the library's communicator (wa_comm_*, csrc/host_comm.inc: SURVEY 8(e)'s three exchanges) with world = 2 and 3
-on a box that has ONE GPU.  RCCL refuses two ranks on one device, so the eleven RCCL entry points the library calls are replaced by
+on a box that has ONE GPU.  RCCL refuses two ranks on one device, so the twelve RCCL entry points the library calls are replaced by
 tests/mock_rccl (LD_PRELOAD; file exchange between processes that share the GPU): what runs is every line of the library around the
 collectives -- packed keys and owners, size prefixes, padding, offsets at a root that is not rank 0, ragged and empty contributions --
 which a world of one rank (tests/test_comm.py, the most a 1-GPU box offers RCCL itself) never exercises.  Not a test of RCCL."""
@@ -32,7 +32,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(world, argv, timeout=240):
+def run_ranks(world, argv, timeout=240, extra_env=None):
     """argv as `world` processes that share GPU 0, the mock in front of librccl; returns their outputs"""
     build_mock()
     shutil.rmtree(MOCK_DIR, ignore_errors=True)
@@ -40,7 +40,7 @@ def run_ranks(world, argv, timeout=240):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60", WA_BENCH_BACKEND="gloo")
+                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60", WA_BENCH_BACKEND="gloo", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -107,6 +107,21 @@ def test_every_exchange_of_the_communicator_between_ranks(world):
             assert np.array_equal(got[k], sent[k]), k
 
 
+    # (5) every rank holds the ROOT's grid (rank 1 voxelised the mesh on the device), and that grid is the oracle's (model_grid_map.hpp:151-298)
+    import oracle_lib as O
+    og = O.grid_from_mesh(O.stl_parse(open(os.path.join(ROOT, "tests", "golden", "cubic.stl"), "rb").read()), 0.0219, 8)
+    for r in range(world):
+        assert np.array_equal(R[r]["b_occ"], og.free), r
+        for a, b in ((R[r]["b_cx"], og.cx), (R[r]["b_cy"], og.cy), (R[r]["b_cz"], og.cz)):
+            assert np.array_equal(a.view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32)), r
+        assert R[r]["b_meta"].tolist() == [og.nx, og.ny, og.nz, 8, int(og.free.sum()), int(np.float32(0.0219).view(np.uint32))], r
+        assert R[r]["b_ids"].tolist() == [4130, 17521], r                     # KA2's start and end voxel
+    # (6) bad arguments on ONE rank: every rank returned an error from that call (nobody hung), and the communicator went on working
+    for r in range(world):
+        assert R[r]["errs"].tolist() == [1, 1, 1], (r, R[r]["errs"])
+        assert R[r]["after"].tolist() == [float(sum(range(world)))]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_pair_planning_sharded_over_ranks_equals_the_single_process_run(world):
     """examples/plan_batch.py (BASELINE config C5 in miniature) as `world` processes: pairs dealt longest-first over the ranks, costs all-gathered,
@@ -134,15 +149,25 @@ def test_cpp_multistart_host_with_three_ranks_on_one_gpu():
     shutil.rmtree(MOCK_DIR, ignore_errors=True)
 
 
-def test_bench_with_two_ranks_on_one_gpu():
-    """bench.py --gpus 2 as the round driver launches it (RANK / WORLD_SIZE / MASTER_* in the environment), both ranks on the one GPU: the library's
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_with_ranks_on_one_gpu(world):
+    """bench.py --gpus N as the round driver launches it (RANK / WORLD_SIZE / MASTER_* in the environment), all ranks on the one GPU: the library's
     exchange through the mock, torch's own barrier and small reductions over gloo (WA_BENCH_BACKEND=gloo; on a multi-GPU node both are RCCL).
     bench.py itself asserts that the reduced global-best history is the MIN of the ranks' gathered histories; here: one JSON line, from rank 0,
-    that counts both ranks' generations and names the owner of the final global best."""
-    outs = run_ranks(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3"], timeout=400)
+    that counts every rank's generations and names the owner of the final global best -- and the C5 STRONG-scaling leg (`c5_sharded`: the grid
+    broadcast from rank 0, the pairs dealt over the ranks, costs all-gathered, paths gathered, the seam order on rank 0), shrunk to fit N
+    processes on one GPU, which bench.py holds against the one-rank run of the same job."""
+    outs = run_ranks(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "30", "--warmup", "3"], timeout=400,
+                     extra_env={"WA_BENCH_C5": "48,9,40", "WA_BENCH_C5_SLOTS": "6"})
     lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and not [l for l in outs[1][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not any(l.startswith("{") for _, o, _ in outs[1:] for l in o.splitlines())
     d = json.loads(lines[0])
+    c5 = d["c5_sharded"]
+    assert c5["scaling"] == "strong" and c5["ranks"] == world and c5["pairs"] == 36 and c5["paths_on_rank0"] == 36 and c5["equals_one_rank_run"] is True
+    assert c5["all_reached"] and 0 < c5["pairs_per_rank_mean"] < 36 and c5["t_search_s"]["imbalance_max_over_mean"] >= 1.0 and c5["pair_generations_per_s"] > 0
+    if world != 2:
+        assert d["n_gpus"] == world and d["scaling"] == "weak"
+        return
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and "wa_acs_allreduce_best" in d["config"]["global_best_allreduce"]
     assert abs(d["value"] - 2 * 30 / (d["ms_per_step"] * 30 * 1e-3)) < 1e-6 * d["value"]      # whole-job rate: both ranks' generations over the slowest rank's time
     assert d["global_best_owner"][0] in (0, 1) and d["global_best_owner"][1] == 0

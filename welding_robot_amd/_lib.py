@@ -96,6 +96,8 @@ SYMBOLS = {
     "wa_comm_allgather_costs": (C.c_int, [_V, _I, _P, _P, _I, _P]),
     "wa_comm_gather_paths": (C.c_int, [_V, _I, _I, _P, _P, _P, _P, _P]),
     "wa_comm_gathered_paths_read": (C.c_int, [_V, _P, _P, _P]),
+    "wa_comm_gathered_paths_counts": (C.c_int, [_V, _P, _P]),
+    "wa_comm_broadcast_grid": (C.c_int, [_V, _I, _V, C.POINTER(_V)]),
     "wa_comm_allreduce_f64": (C.c_int, [_V, _P, _I, _I]),
     "wa_comm_barrier": (C.c_int, [_V]),
     "wa_gtsp_solve": (C.c_int, [_V, _P, _I, _I, _I, C.POINTER(GtspParams), _P, _P, _P, _P, _P]),

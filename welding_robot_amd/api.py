@@ -443,10 +443,19 @@ class Comm:
         self.ctx.check(self.ctx.lib.wa_comm_gather_paths(self.h, root, index.size, _ptr(index), _ptr(lens), _ptr(ids), C.byref(npaths), C.byref(nids)))
         if self.rank != root:
             return {}
+        self.ctx.check(self.ctx.lib.wa_comm_gathered_paths_counts(self.h, C.byref(npaths), C.byref(nids)))   # what the read below copies out
         gi, gl, gd = np.empty(npaths.value, np.int32), np.empty(npaths.value, np.int64), np.empty(nids.value, np.int32)
         self.ctx.check(self.ctx.lib.wa_comm_gathered_paths_read(self.h, _ptr(gi), _ptr(gl), _ptr(gd)))
         off = np.concatenate([[0], np.cumsum(gl)])
         return {int(gi[i]): gd[off[i]:off[i + 1]].copy() for i in range(npaths.value)}
+
+    def broadcast_grid(self, grid, root=0):
+        """wa_comm_broadcast_grid: rank `root` passes its Grid, every other rank None; everybody gets a Grid back (the root its own)"""
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.wa_comm_broadcast_grid(self.h, root, grid.h if grid is not None else None, C.byref(h)))
+        if self.rank == root:
+            return grid
+        return Grid(self.ctx, h)
 
     def allreduce(self, values, op="max"):
         v = np.ascontiguousarray(np.atleast_1d(values), np.float64).copy()
