@@ -111,6 +111,47 @@ def test_comm_id_is_shipped_over_a_socket_without_torch(tmp_path):
     assert wd.ship_unique_id(0, 1, lambda: b"x" * 128) == b"x" * 128
 
 
+def test_comm_id_server_turns_strangers_away_and_serves_every_rank_once(tmp_path):
+    """a port probe, a client of ANOTHER job and a rank that asks twice must not take a real rank's place: rank 0 serves ranks
+    1 and 2 exactly once each, whatever else connects in between; the stranger and the repeat are told no; a rank that never comes makes
+    rank 0 give up after its timeout instead of hanging."""
+    import threading
+    import time
+    port = _free_port()
+    got, errs = {}, {}
+
+    def run(rank, job, key, delay=0.0, world=3, timeout_s=20):
+        time.sleep(delay)
+        try:
+            got[key] = wd.ship_unique_id(rank, world, lambda: bytes(range(128)), port=port, addr="127.0.0.1", timeout_s=timeout_s, job=job)
+        except Exception as e:   # noqa: BLE001
+            errs[key] = e
+
+    def probe():
+        time.sleep(0.3)
+        with socket.create_connection(("127.0.0.1", port), timeout=5) as c:   # says nothing sensible and hangs up
+            c.sendall(b"GET / HTTP/1.0\r\n\r\n")
+
+    th = [threading.Thread(target=run, args=(0, "jobA", "r0")), threading.Thread(target=probe),
+          threading.Thread(target=run, args=(1, "jobB", "stranger", 0.4)),          # same port, another job
+          threading.Thread(target=run, args=(1, "jobA", "r1", 0.6)), threading.Thread(target=run, args=(1, "jobA", "r1 again", 1.2)),
+          threading.Thread(target=run, args=(2, "jobA", "r2", 1.6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert got.get("r0") == got.get("r1") == got.get("r2") == bytes(range(128)), (got.keys(), errs)
+    assert isinstance(errs.get("stranger"), RuntimeError) and "r1 again" in errs and set(got) == {"r0", "r1", "r2"}
+    # a rank that never shows up: rank 0 fails after its timeout
+    port = _free_port()
+    t0 = time.time()
+    try:
+        wd.ship_unique_id(0, 2, lambda: b"y" * 128, port=port, addr="127.0.0.1", timeout_s=1.0, job="jobC")
+        assert False, "rank 0 returned although rank 1 never asked"
+    except TimeoutError:
+        assert time.time() - t0 < 10
+
+
 def test_single_process_helpers_are_identity():
     import torch
     t = torch.tensor([3.0, 1.0])

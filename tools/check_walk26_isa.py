@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from welding_robot_amd import build  # noqa: E402
 
-KERNEL = "_Z12k_walk_dev268WaAcsDev5WaRuniii"
+KERNEL_RE = r"^(_Z\d*k_walk_dev26\w*):"   # (the mangled name follows the signature: found by pattern, not spelled out)
 TOUCH = {250, 251, 252, 253}
 
 
@@ -44,7 +44,10 @@ def vregs(operand_text):
 
 def check(text):
     lines = text.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    hits = [i for i, l in enumerate(lines) if re.match(KERNEL_RE, l)]
+    if len(hits) != 1:
+        return ["expected exactly one k_walk_dev26 kernel in the device code, found %d: %s" % (len(hits), [lines[i][:60] for i in hits])], {}
+    start = hits[0]
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     ins, labels = [], {}
     for l in lines[start + 1:end]:

@@ -67,7 +67,23 @@ def build(force=False, verbose=False, extra=(), out=None):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    if os.environ.get("WA_BUILD_CHECK", "1") != "0":
+        check_isa(extra)
     return out
+
+
+def check_isa(extra=()):
+    """What the 26-neighbour fast loop relies on beyond the compiler's promises (loads issued by one inline statement and waited for by a
+    later one, touch loads in v250..v253) is verified on the assembled device code of THIS toolchain after every build
+    (tools/check_walk26_isa.py; WA_BUILD_CHECK=0 skips): a compiler that puts a copy or a spill between issue and wait fails the
+    build with a message instead of producing wrong walks."""
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_walk26_isa.py")
+    if not os.path.exists(tool) or any(str(e).startswith("-DWA_ASM_SPAN") or str(e) in ("-DWA_STAMPS", "-DWA_ASM_STAMPS") for e in extra):
+        return   # (an installed package without the tools directory; diagnostic builds that restructure the loops)
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libweldacs: the assembled k_walk_dev26 does not keep what its inline statements rely on with this toolchain (%s):\n%s%s"
+                           % (hipcc(), r.stdout, r.stderr[-2000:]))
 
 
 def build_knobs(force=False, verbose=False):

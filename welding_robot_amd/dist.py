@@ -45,45 +45,98 @@ def deal_pairs(pairs, weights, world):
     return shards, load
 
 
-def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0):
+_ID_MAGIC = b"WAID1"
+
+
+def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0, job=None):
     """The 128-byte id of a wa_comm from rank 0 to the other ranks of one job without torch / MPI: rank 0 listens on
-    MASTER_ADDR : MASTER_PORT + 1000 and hands the bytes to world - 1 connections.  make_id() is only called on rank 0."""
+    MASTER_ADDR : MASTER_PORT + 1000 and serves every rank 1 .. world-1 EXACTLY ONCE.  A client introduces itself with a magic
+    word, its rank, the world size and a job tag (`job`, default: TORCHELASTIC_RUN_ID or MASTER_PORT); anything else that connects
+    -- a port probe, a leftover rank of another job, a rank asking twice -- is turned away and does not take a real rank's place.
+    Every socket has a timeout: a rank that never shows up makes rank 0 fail after timeout_s instead of hanging, and a client that
+    was turned away or cut off raises.  make_id() is only called on rank 0."""
     import socket
+    import struct
     import time
     if world == 1:
         return bytes(bytearray(make_id()))
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = port or int(os.environ.get("MASTER_PORT", "29500")) + 1000
+    tag = (job or os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT", "29500")).encode()[:32].ljust(32, b"\0")
+    hello_len = len(_ID_MAGIC) + 8 + 32
+
+    def recv_exact(c, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                return None
+            buf += chunk
+        return buf
+
     if rank == 0:
         uid = bytes(bytearray(make_id()))
         srv = socket.socket()
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
-        srv.listen(world)
-        srv.settimeout(timeout_s)
-        for _ in range(world - 1):
-            c, _a = srv.accept()
-            c.sendall(uid)
-            c.close()
-        srv.close()
+        srv.listen(4 * world)
+        waiting = set(range(1, world))
+        t0 = time.time()
+        try:
+            while waiting:
+                left = timeout_s - (time.time() - t0)
+                if left <= 0:
+                    raise TimeoutError("ship_unique_id: ranks %s never asked for the id" % sorted(waiting))
+                srv.settimeout(left)
+                try:
+                    c, _a = srv.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    c.settimeout(5.0)
+                    hello = recv_exact(c, hello_len)
+                    ok = hello is not None and hello[:len(_ID_MAGIC)] == _ID_MAGIC and hello[len(_ID_MAGIC) + 8:] == tag
+                    if ok:
+                        r, w = struct.unpack("<ii", hello[len(_ID_MAGIC):len(_ID_MAGIC) + 8])
+                        ok = w == world and r in waiting
+                    if ok:
+                        c.sendall(b"OK" + uid)
+                        waiting.discard(r)
+                    else:
+                        c.sendall(b"NO")
+                except OSError:
+                    pass                      # a stray or broken connection: the rank it claimed to be (if any) stays in `waiting`
+                finally:
+                    c.close()
+        finally:
+            srv.close()
         return uid
     t0 = time.time()
     while True:
         try:
             c = socket.create_connection((addr, port), timeout=5.0)
-            break
         except OSError:
             if time.time() - t0 > timeout_s:
                 raise
             time.sleep(0.05)
-    buf = b""
-    while len(buf) < 128:
-        chunk = c.recv(128 - len(buf))
-        if not chunk:
-            raise RuntimeError("ship_unique_id: rank 0 closed the connection early")
-        buf += chunk
-    c.close()
-    return buf
+            continue
+        try:
+            c.settimeout(10.0)
+            c.sendall(_ID_MAGIC + struct.pack("<ii", rank, world) + tag)
+            head = recv_exact(c, 2)
+            if head == b"OK":
+                buf = recv_exact(c, 128)
+                if buf is not None:
+                    return buf
+            elif head == b"NO":
+                raise RuntimeError("ship_unique_id: rank 0 turned rank %d away (another job on this port, or this rank asked twice)" % rank)
+        except OSError:
+            pass                              # cut off mid-way (rank 0 not serving yet / a stale listener): try again until the deadline
+        finally:
+            c.close()
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("ship_unique_id: no id from rank 0 within %.0f s" % timeout_s)
+        time.sleep(0.05)
 
 
 def per_rank_workload(rank, grid_seed=2024, rng_seed=12345):
