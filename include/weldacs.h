@@ -149,10 +149,15 @@ int wa_acs_create_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t 
  * are multiplied by rho every generation (ACSRank_3D.hpp:268-272 restricted to where it can differ).  Every value
  * any kernel reads, and wa_acs_read_pheromone's output, is bit-identical to the dense sweep.  A generation then
  * costs O(deposited voxels) instead of 48 B/voxel and reset_pheromone O(deposited voxels) instead of 24 B/voxel:
- * meant for many pair searches on large grids (BASELINE config C5).  DEV mode, 6 neighbours, <= 2048 ants and
+ * meant for many pair searches on large grids (BASELINE config C5).  DEV mode, <= 2048 ants and
  * <= 64 depositing ranks only (WA_ERR_ARG at wa_acs_begin otherwise); wa_acs_evaporate is not available. */
 int wa_acs_create_lazy(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
                        int64_t path_capacity, wa_acs **out);
+/* ... with 6 or 26 neighbours (round 5): the 26-neighbour variant the reference stubs out (ACSRank_3D.hpp:361-388) swept 26 x 8 B x N
+ * per search and generation in its dense form -- 3.5 GB at 256^3 -- which kept it a small-grid feature; lazily evaporated it runs at
+ * pair-planning scale.  Same restrictions as wa_acs_create_lazy. */
+int wa_acs_create_lazy_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int32_t max_colony,
+                          int64_t path_capacity, int32_t neighbourhood, wa_acs **out);
 void wa_acs_destroy(wa_acs *s);
 /* device bytes a solver of this shape takes: per slot, per heuristic field (the pool holds one per distinct END point of a
  * batch, at least min(n_slots, 4)) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.

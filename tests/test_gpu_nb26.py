@@ -170,6 +170,67 @@ def test_nb26_shorter_paths_than_6_neighbours(ctx):
     assert out[26][0] < out[6][0] and len(out[26][1]) < len(out[6][1])
 
 
+def test_nb26_lazy_evaporation_equals_the_oracles_dense_sweep(ctx):
+    """wa_acs_create_lazy_nb(..., 26) (round 5): the 26-neighbour search without the 26 x 8 B x N sweep.  Pair flow on ten slots: reset()
+    between rounds (rewrites the dirty records only), a round WITHOUT reset (clean scalar and dirty set carry over), back to initFromGridMap
+    (mode switch: the full pass), another rho (pending evaporations flushed with the rho they belong to), a tiny tabu table (spill to the
+    bitmap) -- cost, best path and the WHOLE 26-edge field of every slot against the oracle after every round."""
+    og = ogrid("cubic.stl", "0.0219", 8)
+    dg = dgrid_from(ctx, og)
+    nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12)]
+    ids = [og.resolve(og.node_pt(*n)) for n in nodes]
+    pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+    os.environ["WA_HASH_LOG2"] = "7"
+    try:
+        sb = api.AcsSolver(ctx, dg, n_slots=len(pairs), max_colony=12, neighbourhood=26, lazy=True)
+    finally:
+        del os.environ["WA_HASH_LOG2"]
+    oracles = [O.Acs(og, nb=26) for _ in pairs]
+    rounds = [("reset", 0.8, 30), ("reset", 0.8, 25), ("carry", 0.8, 17), ("init", 0.8, 20), ("carry", 0.9, 9), ("reset", 0.9, 12)]
+    for rnd, (step, rho, iters) in enumerate(rounds):
+        p = api.default_params(max_iteration=iters, predict=0.75, rng_mode=api.RNG_DEV, seed=2024 + rnd, rho=rho)
+        if step == "reset":
+            sb.reset_pheromone(1.0)
+        elif step == "init":
+            sb.init_pheromone(1.0)
+            oracles = [O.Acs(og, nb=26) for _ in pairs]
+        sb.solve(p, [ids[i] for i, _ in pairs], [ids[j] for _, j in pairs], streams=[k + 100 * rnd for k in range(len(pairs))])
+        for k, (i, j) in enumerate(pairs):
+            a = oracles[k]
+            if step == "reset":
+                a.reset(1.0)
+            a.solve(ids[i], ids[j], iters, 0.75, mode=O.DEV, seed=2024 + rnd, stream=k + 100 * rnd, rho=rho)
+            cost, path, _ = sb.result(k)
+            assert bits(cost) == bits(a.best_L), (rnd, k)
+            if np.isfinite(cost):
+                assert np.array_equal(path, a.best_path()[0]), (rnd, k)
+            assert np.array_equal(bits(sb.pheromone(k)), bits(a.pheromone())), (rnd, k)
+    sb.close()
+
+
+def test_nb26_lazy_equals_dense_on_a_synthetic_grid_with_a_big_colony(ctx):
+    """64^3, 128 ants (26 depositing ranks), 40 generations: the fast loop with the stamp behind the record loads, the replay table built
+    from stamped records, the background pass -- lazy == dense == oracle on trace, every ant and the whole field"""
+    og = O.synth_grid(64, seed=77, occ_prob=0.10)
+    free = np.nonzero(og.free)[0]
+    sid, eid = int(free[0]), int(free[-1])
+    dg = dgrid_from(ctx, og)
+    a = O.Acs(og, nb=26)
+    tr = a.solve(sid, eid, 40, 200.0, fixed_colony=128, mode=O.DEV, seed=9, stream=4)
+    for lazy in (True, False):
+        s = api.AcsSolver(ctx, dg, 1, 128, neighbourhood=26, lazy=lazy)
+        p = api.default_params(max_iteration=40, predict=200.0, fixed_colony=128, rng_mode=api.RNG_DEV, seed=9)
+        s.init_pheromone(1.0)
+        s.solve(p, sid, eid, streams=[4])
+        t = s.trace()
+        assert np.array_equal(t["steps"], tr["steps"]) and np.array_equal(bits(t["bestL"]), bits(tr["bestL"])) and np.array_equal(t["finite"], tr["finite"]), lazy
+        L, lens = s.ants()
+        olens, oL = a.last_ants()
+        assert np.array_equal(lens, olens) and np.array_equal(bits(L), bits(oL)), lazy
+        assert np.array_equal(bits(s.pheromone()), bits(a.pheromone())), lazy
+        s.close()
+
+
 def test_nb_argument_is_checked(ctx):
     og = O.synth_grid(8, seed=1)
     dg = dgrid_from(ctx, og)

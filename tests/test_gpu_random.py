@@ -77,7 +77,7 @@ def test_random_problems_dense_lazy_and_26(ctx, chunk):
         try:
             bound = fixed if fixed else int(0.35 * predict / float(og.precision))
             lazy_ok = bound <= 2048 and int(0.2 * bound) + 1 <= 64
-            for nb, lazy in ((6, False), (6, True), (26, False)):
+            for nb, lazy in ((6, False), (6, True), (26, False), (26, True)):
                 if lazy and not lazy_ok:
                     continue
                 try:
@@ -190,7 +190,7 @@ def test_random_medium_problems(ctx, chunk):
         iters = int(rs.choice([8, 20, 45])) if fixed < 2000 else 3
         seed, stream = int(rs.randint(1 << 30)), int(rs.randint(9))
         lazy_ok = fixed <= 2048 and int(0.2 * fixed) + 1 <= 64
-        for nb, lazy in ((6, False), (6, True), (26, False)):
+        for nb, lazy in ((6, False), (6, True), (26, False), (26, True)):
             if lazy and not lazy_ok:
                 continue
             if nb == 26 and fixed > 400:

@@ -37,8 +37,15 @@ def test_walk26_loop_keeps_its_loads_and_registers_to_itself(device_asm):
 def test_walk26_checker_sees_what_it_is_there_for(device_asm):
     """the checker on doctored code: the deferred wait removed, a copy of a freshly requested record, a stray use of a touch register"""
     chk = _checker()
+    import re
     lines = device_asm.split("\n")
-    k0 = next(i for i, l in enumerate(lines) if l.startswith(chk.KERNEL + ":"))
+    heads = [i for i, l in enumerate(lines) if re.match(chk.KERNEL_RE, l)]
+    assert len(heads) == 2                                   # the dense field's and the lazily evaporated field's instantiation
+    for k0 in heads:
+        _doctored(chk, lines, k0)
+
+
+def _doctored(chk, lines, k0):
     k1 = next(i for i in range(k0, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[k0:k1]
     w = [i for i, l in enumerate(body) if l.strip() == "s_waitcnt vmcnt(4)"]

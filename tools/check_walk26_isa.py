@@ -43,11 +43,21 @@ def vregs(operand_text):
 
 
 def check(text):
+    """every instantiation of k_walk_dev26 (dense field, lazily evaporated field) is checked; the summary describes the first"""
     lines = text.split("\n")
     hits = [i for i, l in enumerate(lines) if re.match(KERNEL_RE, l)]
-    if len(hits) != 1:
-        return ["expected exactly one k_walk_dev26 kernel in the device code, found %d: %s" % (len(hits), [lines[i][:60] for i in hits])], {}
-    start = hits[0]
+    if not hits:
+        return ["no k_walk_dev26 kernel in the device code"], {}
+    problems, info = [], None
+    for start in hits:
+        p, i = check_kernel(lines, start)
+        problems += ["%s: %s" % (lines[start].split(":")[0][:40], x) for x in p]
+        info = info or i
+    info["kernels"] = len(hits)
+    return problems, info
+
+
+def check_kernel(lines, start):
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     ins, labels = [], {}
     for l in lines[start + 1:end]:
@@ -128,7 +138,7 @@ def main():
         for p in problems:
             print("  " + p)
         return 1
-    print("k_walk_dev26 ISA check ok: %(instructions)d instructions, %(deferred_pairs)d record-load pairs with a deferred wait, "
+    print("k_walk_dev26 ISA check ok (%(kernels)d instantiation(s)): %(instructions)d instructions, %(deferred_pairs)d record-load pairs with a deferred wait, "
           "%(touch_loads)d touch loads in v250..v253, highest VGPR of its own v%(highest_own_vgpr)d" % info)
     return 0
 

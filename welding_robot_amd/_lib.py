@@ -56,6 +56,7 @@ SYMBOLS = {
     "wa_acs_create": (C.c_int, [_V, _V, _I, _I, _I64, C.POINTER(_V)]),
     "wa_acs_create_nb": (C.c_int, [_V, _V, _I, _I, _I64, _I, C.POINTER(_V)]),
     "wa_acs_create_lazy": (C.c_int, [_V, _V, _I, _I, _I64, C.POINTER(_V)]),
+    "wa_acs_create_lazy_nb": (C.c_int, [_V, _V, _I, _I, _I64, _I, C.POINTER(_V)]),
     "wa_acs_destroy": (None, [_V]),
     "wa_acs_memory_estimate": (C.c_int, [_V, _I, _I64, _I, _I, _P, _P, _P]),
     "wa_acs_straggler_pool_bytes": (C.c_int, [_V, _I, _I, _I64, _I, _I, _P]),

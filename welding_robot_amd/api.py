@@ -190,8 +190,7 @@ class AcsSolver:
         self.ctx, self.grid, self.n_slots, self.max_colony, self.nb = ctx, grid, n_slots, max_colony, neighbourhood
         h = C.c_void_p()
         if lazy:
-            assert neighbourhood == 6
-            ctx.check(ctx.lib.wa_acs_create_lazy(ctx.h, grid.h, n_slots, max_colony, path_capacity, C.byref(h)))
+            ctx.check(ctx.lib.wa_acs_create_lazy_nb(ctx.h, grid.h, n_slots, max_colony, path_capacity, neighbourhood, C.byref(h)))
         else:
             ctx.check(ctx.lib.wa_acs_create_nb(ctx.h, grid.h, n_slots, max_colony, path_capacity, neighbourhood, C.byref(h)))
         self.h = h
@@ -366,11 +365,11 @@ def unpack_best_key(key, lib_path=None):
     return np.float32(c.value), r.value, s_.value
 
 
-def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True):
+def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True, neighbourhood=6):
     """Concurrent pair searches for `n_pairs` searches on this device -- the rule of the drop-in ACS_Rank::slots_for
     (welding_robot_amd/include/core/ACSRank_3D.hpp): 3/4 of the free memory but at most ~200 GB of fields, at most three
     rounds of resident walk blocks, then whole batches of equal size.  Returns (slots, batches)."""
-    per_slot, per_field, fixed = memory_estimate(grid, colony, 0, 6, lazy)
+    per_slot, per_field, fixed = memory_estimate(grid, colony, 0, neighbourhood, lazy)
     per_slot += 20 * max_iteration
     free, _ = ctx.memory_info()
     fields = min(max(4, n_ends), 8)

@@ -65,6 +65,11 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
     wa_off26(k, dx, dy, dz);
     const int32_t dk = dz * D.d.nxy + dy * D.d.nx + dx;
     const int32_t last_id = (int32_t)D.d.n - 1;
+    // lazy evaporation (see wa_table_rows): a best-path node that never received a deposit holds the clean value of the field as it stands
+    // now, a deposited one that received nothing this generation may have evaporations pending (read-side catch-up)
+    const uint32_t *stamp = D.stamp ? D.stamp + (int64_t)slot * D.d.n : nullptr;
+    const float clean_now = ctl->clean[ctl->gen & 1];
+    const uint32_t evap_tab = ctl->evap_base + (uint32_t)ctl->gen;   // the fused launch already counted this generation
     for (int32_t i = w; i < blen - 1; i += n_waves) {   // decisions exist at nodes 0 .. blen-2
         const int32_t v = bpath[i] & WaNbT<26>::IDM;
         float p = -0.f, h = 0.f;
@@ -73,6 +78,10 @@ __device__ __forceinline__ void wa_table26_rows(const WaAcsDev &D, const WaRun &
             const int64_t e = (int64_t)v * 26 + lane;
             p = pher[e];
             h = heur[e];
+            if (stamp) {
+                const uint32_t stv = stamp[v];
+                p = stv == 0 ? copysignf(clean_now, p) : copysignf(wa_catch_up(fabsf(p), evap_tab + 1u - stv, R.rho), p);
+            }
             int32_t nb = v + dk;
             nb = nb < 0 ? 0 : nb > last_id ? last_id : nb;    // (an out-of-bounds edge is inadmissible by its sign bit whatever is found here)
             const uint32_t mk = mark[nb];
@@ -119,6 +128,8 @@ __global__ __launch_bounds__(256) void k_apply_table26(WaAcsDev D, WaRun R)
     __shared__ float s_d[1024];
     __shared__ float s_dep[64];
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    // lazy evaporation: voxels that became dirty in this generation join the swept set from the next sweep on (see k_apply_table)
+    if (D.dcount && blockIdx.x == 0 && tid == 0) D.dcount[slot * 2] = D.dcount[slot * 2 + 1];
     if (D.pool_n && blockIdx.x == 0) {   // stragglers: the next generation starts with no arrivals and an empty pool of its own (see k_apply_table)
         const WaStrag sg = wa_strag_of(D, slot);
         sg.arr_len[tid] = 0xffffffffu;
@@ -174,13 +185,18 @@ __device__ __forceinline__ int wa_walk_replay26(const float *__restrict__ T, int
     }
 }
 
-template <int MODE>
+// SPARSE: the field of a lazily evaporating solver (round 5; see WaAcsDev and wa_walk_fast): the stamp of the voxel the ant stands on
+// decides -- 0: never deposited, every admissible edge is worth the clean value; else the stored value with the evaporations it has
+// missed applied one by one.  The stamp travels with the voxel's record (one more load behind the two record loads).
+template <int MODE, bool SPARSE = false>
 __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant, int32_t start,
                                               int32_t end, uint64_t antkey, int32_t *tab, int hash_log2, int32_t &rng_rs,
                                               int32_t &rng_f, int32_t &rng_b, int32_t *flags_out, int32_t rlen,
                                               int32_t cut_n = 0x7fffffff, int32_t *res_words = nullptr, int32_t res_len = 0, float res_L = 0.f,
-                                              int32_t gen = 0, int32_t bits_row = -1, bool drain = false)
+                                              int32_t gen = 0, int32_t bits_row = -1, bool drain = false, float clean = 0.f, uint32_t evap_now = 0u)
 {
+    const uint32_t *stamp = SPARSE ? D.stamp + (int64_t)slot * D.d.n : nullptr;
+    const float clean_info = SPARSE ? wa_powi(clean, R.alpha) : 0.f;   // power() of the clean value, once per walk
     // Stragglers (see wa_walk_one / k_walk_dev): step lengths differ per move type here, so the arrivals publish the bits of
     // their L (positive floats order like unsigned integers) and an ant compares the L it has accumulated so far -- a lower bound of
     // its final L, every step adds a positive length -- against them.  res_words != nullptr: a resume block, which finishes the
@@ -303,22 +319,30 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         // kernel needs ~30) and stay in flight across the `s_waitcnt vmcnt(4)`.  (Loads the pass does not see only make its own waits
         // stricter than it thinks, never weaker.)
         float p = -0.f, h = 0.f;
+        uint32_t sv = 1u;                                                          // SPARSE: the stamp of the voxel whose record p / h are
         {
             const uint32_t off = (uint32_t)cur * 104u + lane_off;
             asm volatile("global_load_dword %0, %2, %3\n global_load_dword %1, %2, %4\n s_waitcnt vmcnt(0)"
                          : "=&v"(p), "=&v"(h) : "v"(off), "s"(pher_b), "s"(heur_b) : "memory");
+            if (SPARSE) sv = stamp[cur];
         }
+        const char *stamp_b = reinterpret_cast<const char *>(stamp);
         // tabu probe of neighbour k (:145): ends on the key (visited) or on an empty slot (not visited; where the key would go)
         uint32_t hs = ((uint32_t)cur * 2654435761u + hk) >> T.shift;
         int32_t tv = tab[hs];
         bool alive = true, cut = false;
         int32_t em = 63;   // the straggler check runs when (node count & em) == 0: at block boundaries, every 16 nodes once shorter ants have arrived
         while (len <= spill_at && len < (int32_t)D.path_cap) {
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(p), "+v"(h));                 // this step's records; the touch loads stay in flight
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(p), "+v"(h), "+v"(sv));       // this step's records; the touch loads stay in flight
             const int32_t key = cur + dk;
             while (tv != key && tv != WA_HASH_EMPTY) { hs = (hs + 1) & T.mask; tv = tab[hs]; }   // (rare: the slot held another key)
             const bool adm = lane < 26 && (__float_as_uint(p) >> 31) == 0 && tv != key;   // sign bit: out of bounds or occupied (:148)
-            const float a = adm ? fabsf(p) * h : 0.f;                              // :154 (alpha == 1)
+            float mag = fabsf(p);
+            if (SPARSE) {   // every lane holds the same voxel's stamp: uniform, so scalar control flow
+                const uint32_t stv = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
+                mag = stv == 0 ? clean_info : wa_catch_up(mag, evap_now + 1u - stv, R.rho);
+            }
+            const float a = adm ? mag * h : 0.f;                                   // :154 (alpha == 1)
             const unsigned long long mb = __ballot(adm);
             if (mb == 0) { L = INFINITY; alive = false; break; }                   // :162-166
             float t = 0.f + a, c = 0.f + a;
@@ -340,6 +364,10 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
             {
                 const uint32_t off = (uint32_t)next * 104u + lane_off;
                 asm volatile("global_load_dword %0, %2, %3\n global_load_dword %1, %2, %4" : "=&v"(p), "=&v"(h) : "v"(off), "s"(pher_b), "s"(heur_b) : "memory");
+                if (SPARSE) {   // ... and its stamp, behind them and in front of the touches (vector memory returns in order: vmcnt(4) covers it)
+                    const uint32_t soff = (uint32_t)next * 4u;
+                    asm volatile("global_load_dword %0, %1, %2" : "=&v"(sv) : "v"(soff), "s"(stamp_b) : "memory");
+                }
             }
             if (lane == 0) tab[slot_pick] = next;                                  // addNextNode :75 (before the probe below: LDS is in order)
             hs = ((uint32_t)next * 2654435761u + hk) >> T.shift;
@@ -420,7 +448,12 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         }
         asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(w3));   // last step's cache-warming loads retire before these
         if (lane < 26 && (__float_as_uint(p) >> 31) == 0) adm = !tabu_has(T, cur + dk);   // sign bit: out of bounds or occupied
-        const float info = wa_powi(fabsf(p), R.alpha) * h;                        // :154
+        float pa = wa_powi(fabsf(p), R.alpha);
+        if (SPARSE) {
+            const uint32_t stv = stamp[cur];
+            pa = stv == 0 ? clean_info : wa_powi(wa_catch_up(fabsf(p), evap_now + 1u - stv, R.rho), R.alpha);
+        }
+        const float info = pa * h;                                                // :154
         const unsigned long long mb = __ballot(adm);
         if (mb == 0) { L = INFINITY; break; }                                     // :162-166
         // the two ORDERED sums of selectNext as whole-wave DPP chains over the zero-padded candidates:
@@ -482,6 +515,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
 }
 
 // walk_flags bit 5: this generation may hand its stragglers over (the next launch of the call carries resume blocks, see k_walk_dev)
+template <bool SPARSE>
 __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -489,7 +523,7 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
     const WaSlotCtl *c = &D.ctl[slot];
     const int32_t colony = c->colony[gen & 1];
     int32_t f = 0, b = 0, rs_unused = 0;
-    if (D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
+    if (!SPARSE && D.pool_n && (int32_t)blockIdx.x >= D.max_colony) {
         // ---- resume block: a straggler of generation gen - 1 finishes its walk here, on that generation's field
         const int32_t r = (int32_t)blockIdx.x - D.max_colony, pg = (gen - 1) & 1;
         const WaStrag sg = wa_strag_of(D, slot);
@@ -510,9 +544,10 @@ __global__ __launch_bounds__(64) void k_walk_dev26(WaAcsDev D, WaRun R, int hash
     const int32_t rlen = (D.rtab && c->bestL != INFINITY) ? c->best_len : 0;
     // an ant with a larger L than floor(lambda - 1) + 1 arrivals cannot be among the depositing ranks (:200) nor be the iteration's best
     int32_t cut_n = 0x7fffffff;
-    if ((walk_flags & 32) && D.pool_n && R.alpha == 1) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
+    if (!SPARSE && (walk_flags & 32) && D.pool_n && R.alpha == 1) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
     if (cut_n < 1) cut_n = 1;
-    wa_walk_one26<1>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, cut_n, nullptr, 0, 0.f, gen);
+    wa_walk_one26<1, SPARSE>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, cut_n, nullptr, 0, 0.f, gen,
+                             -1, false, c->clean[gen & 1], c->evap_base + (uint32_t)gen);
 }
 
 __global__ __launch_bounds__(64) void k_walk_ref26(WaAcsDev D, WaRun R, int hash_log2, int32_t gen)

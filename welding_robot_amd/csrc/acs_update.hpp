@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
                 const uint32_t old = atomicExch(&stamp[v], target);
                 if (old == target) continue;
 #pragma unroll
-                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho);
+                for (int k = 0; k < NB; k++) ph[(int64_t)v * NB + k] = wa_catch_up(ph[(int64_t)v * NB + k], target - old, rho);
             }
         }
         return;
@@ -482,13 +482,13 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
                 const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
                 D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
 #pragma unroll
-                for (int k = 0; k < 6; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
-                    const float st0 = ph[(int64_t)v * 6 + k];
-                    ph[(int64_t)v * 6 + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
+                for (int k = 0; k < NB; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
+                    const float st0 = ph[(int64_t)v * NB + k];
+                    ph[(int64_t)v * NB + k] = copysignf(fabsf(st0) == 0.f ? 0.f : clean_next, st0);
                 }
             } else if (old != target) {   // deposited before: apply the evaporations it has missed since
 #pragma unroll
-                for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, R.rho);
+                for (int k = 0; k < NB; k++) ph[(int64_t)v * NB + k] = wa_catch_up(ph[(int64_t)v * NB + k], target - old, R.rho);
             }
         }
     }
@@ -605,6 +605,7 @@ __global__ void k_lazy_clear(WaAcsDev D, int32_t slot0, int32_t cnt, float p0)
 }
 // reset() of a lazy slot whose init mode and p0 are unchanged: only the dirty records are rewritten
 // (same values as k_init_pheromone) and their flags cleared.  grid.y = slots.
+template <int NB>
 __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
 {
     const int32_t slot = slot0 + blockIdx.y;
@@ -616,13 +617,14 @@ __global__ __launch_bounds__(256) void k_lazy_restore(WaAcsDev D, int32_t slot0,
         const int32_t id = list[q];
         const int32_t x = id % D.d.nx, y = (id / D.d.nx) % D.d.ny, z = id / D.d.nxy;
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int32_t X = x + (k == 2 ? -1 : k == 3 ? 1 : 0), Y = y + (k == 1 ? -1 : k == 4 ? 1 : 0),
-                          Z = z + (k == 0 ? -1 : k == 5 ? 1 : 0);
+        for (int k = 0; k < NB; k++) {
+            int dx, dy, dz;
+            wa_edge_offset<NB>(k, dx, dy, dz);
+            const int32_t X = x + dx, Y = y + dy, Z = z + dz;
             const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
-            const bool adm = inb && D.occ[id + wa_delta(k, D.d.nx, D.d.nxy)] != 0;
+            const bool adm = inb && D.occ[id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
             const float v = (inb || mode == 1) ? p0 : 0.f;
-            ph[(int64_t)id * 6 + k] = adm ? v : -v;
+            ph[(int64_t)id * NB + k] = adm ? v : -v;
         }
         stamp[id] = 0;
     }
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(256) void k_lazy_faces(WaAcsDev D, int32_t slot0, f
 }
 // bring every deposited record current (before a solve that evaporates with a different rho: the pending
 // multiplications belong to the old one).  grid.y = slots.
+template <int NB>
 __global__ __launch_bounds__(256) void k_lazy_flush(WaAcsDev D, float rho_old)
 {
     const int32_t slot = blockIdx.y;
@@ -682,18 +685,19 @@ __global__ __launch_bounds__(256) void k_lazy_flush(WaAcsDev D, float rho_old)
         const uint32_t old = stamp[v];
         if (old == target) continue;
 #pragma unroll
-        for (int k = 0; k < 6; k++) ph[(int64_t)v * 6 + k] = wa_catch_up(ph[(int64_t)v * 6 + k], target - old, rho_old);
+        for (int k = 0; k < NB; k++) ph[(int64_t)v * NB + k] = wa_catch_up(ph[(int64_t)v * NB + k], target - old, rho_old);
         stamp[v] = target;
     }
 }
 
 // the field as the dense sweep would have left it: deposited records with their pending evaporations applied,
 // clean records at the clean value
+template <int NB>
 __global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, WaRun R, int32_t slot, float *out)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= D.d.n * 6) return;
-    const int64_t v = e / 6;
+    if (e >= D.d.n * NB) return;
+    const int64_t v = e / NB;
     const float st0 = D.pher[(int64_t)slot * D.pher_stride + e];
     const WaSlotCtl *c = &D.ctl[slot];
     const float clean = c->clean[c->gen & 1];
