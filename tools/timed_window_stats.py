@@ -27,6 +27,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     out = []
+    series = {}
     t_first, t_last, total = None, None, 0.0
     for label, key in LOOP:
         mine = [(a, b) for a, b, k in rows if key in k]
@@ -34,6 +35,7 @@ def main():
         extra = len(mine) - (W + K)
         win = mine[W:W + K]
         us = [(b - a) / 1e3 for a, b in win]
+        series[key] = us
         out.append(dict(kernel=key, role=label, launches_in_window=len(win), total_us=sum(us), avg_us=sum(us) / len(us), min_us=min(us), max_us=max(us),
                         dispatches_outside_window=W + extra))
         total += sum(us)
@@ -54,6 +56,15 @@ def main():
     alg = float(d["roofline"]["algorithmic_bytes_per_launch"])
     print("  roofline from the window alone: %.0f B / %.2f us = %.2f TB/s = %.3f of 8 TB/s   (bench.py's event-based frac: %.3f)"
           % (alg, sweep["avg_us"], alg / sweep["avg_us"] / 1e6, alg / sweep["avg_us"] / 1e6 / 8.0, d["roofline"]["frac"]))
+    if "--ranges" in sys.argv:   # where the time goes, by generation of the search (the timed region starts at generation 0)
+        print("  by generation range (average us per launch: walk / sweep + rank + mark / apply + table; longest walk launch of the range):")
+        for lo, hi in ((0, 10), (10, 20), (20, 30), (30, 40), (40, 60), (60, 80), (80, 100), (100, 200), (200, 500)):
+            if lo >= K:
+                break
+            hi = min(hi, K)
+            w, f, a = (series[k][lo:hi] for _, k in LOOP)
+            print("    generations %3d-%3d: %7.2f / %6.2f / %6.2f   sum %7.2f   longest walk %7.2f" % (lo, hi - 1, sum(w) / len(w), sum(f) / len(f), sum(a) / len(a),
+                                                                                                    (sum(w) + sum(f) + sum(a)) / len(w), max(w)))
     if "--csv" in sys.argv:
         with open(sys.argv[sys.argv.index("--csv") + 1], "w") as f:
             w = csv.DictWriter(f, fieldnames=list(out[0]))

@@ -47,7 +47,25 @@
 #define WA_ASM_WARM_ADDR_SELF "v_add_u32 v83, s40, v66\n"
 #define WA_ASM_WARM0_SELF "global_load_dwordx4 v[86:89], v83, %[pher]\n"
 #define WA_ASM_WARM1_SELF "global_load_dwordx4 v[90:93], v83, %[heur]\n"
+// -DWA_EXP_STORE=1 (experiment, tools/walk_ab.py; round 5): what would a per-step global STORE cost the lone search's step -- the insert of a
+// visited bitmap kept in device memory instead of the LDS hash (task 5)?  Vector memory operations retire in order and the
+// loop's waits are exact vmcnt counts: a store issued in step t must have been acknowledged before the records requested behind it can
+// count as arrived (step t + 2).  The variant stores the step's path register over the path block that is being collected (rewritten in
+// full when the block completes: harmless) -- four address instructions + one global_store_dword, vmcnt counts raised by one;
+// -DWA_EXP_STORE=2: the four instructions without the store.  Dense loop with touch loads only.
+#if defined(WA_EXP_STORE)
+#define WA_ASM_EXP_ADDR "s_and_b32 s46, m0, 0xffffffc0\n" "s_lshl_b32 s46, s46, 2\n" "v_lshlrev_b32 v94, 2, v64\n" "v_add_u32 v94, s46, v94\n"
+#if WA_EXP_STORE == 1
+#define WA_ASM_EXP_STORE WA_ASM_EXP_ADDR "global_store_dword v94, %[pbuf], %[path]\n"
+#define WA_ASM_VMWAIT_SELF "s_waitcnt vmcnt(5)\n"
+#else
+#define WA_ASM_EXP_STORE WA_ASM_EXP_ADDR
 #define WA_ASM_VMWAIT_SELF "s_waitcnt vmcnt(4)\n"
+#endif
+#else
+#define WA_ASM_EXP_STORE ""
+#define WA_ASM_VMWAIT_SELF "s_waitcnt vmcnt(4)\n"
+#endif
 #define WA_ASM_VMWAIT_LAZY_SELF "s_waitcnt vmcnt(5)\n"          /* (one more load per step: the stamp) */
 #define WA_ASM_WARM_ADDR_NONE ""
 #define WA_ASM_WARM0_NONE "s_nop 0\n"                           /* (keeps the compares four instructions away from their scalar consumers) */
@@ -370,6 +388,7 @@
     "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
     "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
     "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
+    WA_ASM_EXP_STORE                                                                                              \
     WA_SPAN_7                                                                                                     \
     WA_ASM_ACTIVE_##W                                             /* next active block = position of the pick (low 6 bits count) */ \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \

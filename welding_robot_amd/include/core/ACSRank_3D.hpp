@@ -480,7 +480,7 @@ private:
         int colony = fixed_colony > 0 ? fixed_colony : (int)(0.35 * (double)predict / (double)precision);
         return colony < 1 ? 1 : colony;
     }
-    bool lazy_ok(int colony) const { return lazy && rng_mode == WA_RNG_DEV && neighbourhood == 6 && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64; }
+    bool lazy_ok(int colony) const { return lazy && rng_mode == WA_RNG_DEV && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64; }   // (6 or 26 neighbours: wa_acs_create_lazy_nb)
     // Concurrent pair searches of a shard with `n_pairs` searches.  Upper bound from memory: 3/4 of what the device has free
     // (ctx == NULL: the primary context), and never more than ~200 GB of fields -- past that footprint the walk's random record
     // loads slow down (measured on BASELINE config C5: 224 slots of 0.85 GB run 2 016 searches in 0.57 s, 252 in 1.0 s).  The
@@ -523,7 +523,7 @@ private:
         // shard's size)
         const int want = rng_mode == WA_RNG_REF ? 1 : (slots_override > 0 ? slots_override : std::max(1, concurrent_pairs));
         if (ctx == weldacs_dropin::context()) slots = want;
-        int rc = lazy_ok(colony) ? wa_acs_create_lazy(ctx, g, want, colony, 0, out) : wa_acs_create_nb(ctx, g, want, colony, 0, neighbourhood, out);
+        int rc = lazy_ok(colony) ? wa_acs_create_lazy_nb(ctx, g, want, colony, 0, neighbourhood, out) : wa_acs_create_nb(ctx, g, want, colony, 0, neighbourhood, out);
         if (rc == WA_OK) rc = wa_acs_init_pheromone(*out, -1, 1.0f);
         return rc;
     }
