@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel split of one C5-shaped batch (256^3, 48 concurrent pair searches, 24 ants, 150 generations), lazy solver."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from welding_robot_amd import api, synth

@@ -2,7 +2,7 @@
 """Lazy evaporation (wa_acs_create_lazy) beside the dense sweep on the benchmark search (128^3, 256 ants, 500 generations,
 per-dispatch profiling off): generations/s, and that trace, path and the full pheromone field are identical."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from welding_robot_amd import api, synth

@@ -52,7 +52,7 @@ python3 tools/walk_direct_ab.py --c5 --direct 0 --reps 3 --batches > $O/c5_batch
 python3 tools/pipeline_curve.py --P 1,2,4,8,16,32 --G 1,2 --kinds dense,lazy > $O/pipeline_curve.jsonl 2>&1
 python3 tools/sweep_nt.py > $O/sweep_nt.txt 2>&1
 python3 tools/ref_time.py 500 > $O/ref_time.txt 2>&1
-python3 tests/tools/nb26_time.py 300 > $O/nb26_time.txt 2>&1
+python3 tests/tools/nb26_time.py 300 > $O/nb26_time.txt 2>&1   # (under tests/: it times the CPU oracle beside the kernel, and only tests may load oracle/)
 python3 examples/plan_batch.py --grid 256 --points 64 --lazy > $O/plan_batch_c5.jsonl 2>&1
 python3 examples/plan_batch.py --grid 256 --points 64 --lazy >> $O/plan_batch_c5.jsonl 2>&1
 build/vmm_probe 64 > $O/vmm_probe.txt 2>&1
