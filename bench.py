@@ -395,6 +395,7 @@ def c5_full_extra(ctx):
         t_pairs = time.perf_counter() - t0 - pb.plan.last_create_s
         st1 = ctx.cache_stats()
         runs.append({"t_solver_create_s": pb.plan.last_create_s, "t_pairs_s": t_pairs, "slots": pb.plan.last_slots,
+                     "batch_solve_reset_read_s": pb.plan.last_batch_s,
                      "cache_hit_gib": (st1["hit_bytes"] - st0["hit_bytes"]) / GiB, "cache_miss_gib": (st1["miss_bytes"] - st0["miss_bytes"]) / GiB,
                      "released_to_driver_gib": (st1["released_bytes"] - st0["released_bytes"]) / GiB, "out_of_memory_events": st1["oom_events"] - st0["oom_events"],
                      "kept_gib_after": st1["kept_bytes"] / GiB})

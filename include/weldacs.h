@@ -160,7 +160,7 @@ int wa_acs_create_lazy_nb(wa_ctx *ctx, const wa_grid *grid, int32_t n_slots, int
                           int64_t path_capacity, int32_t neighbourhood, wa_acs **out);
 void wa_acs_destroy(wa_acs *s);
 /* device bytes a solver of this shape takes: per slot, per heuristic field (the pool holds one per distinct END point of a
- * batch, at least min(n_slots, 4)) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.
+ * batch, at least min(n_slots, 4) -- from 32 slots on n_slots / 8, between 8 and 24) and once per solver; the per-generation trace (20 B per slot and generation) comes on top.
  * Nothing is allocated.  The drop-in ACS_Rank sizes the concurrent pair searches of a device from this and
  * wa_ctx_memory_info (ACSRank_3D.hpp:472-499 runs them one after another).  The straggler pools of small dense solvers come on top:
  * wa_acs_straggler_pool_bytes. */

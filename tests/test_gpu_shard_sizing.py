@@ -31,7 +31,7 @@ def test_memory_estimate_matches_the_allocator(ctx, lazy, colony, nb):
         used = before - after
         pools = api.straggler_pool_bytes(g, slots, colony, 0, nb, lazy)
         assert (pools > 0) == (not lazy and slots <= 16 and colony <= 256)   # dense solvers of up to 16 slots and 256 ants hand their stragglers over, per slot
-        want = slots * per_slot + min(slots, 4) * per_field + fixed + pools
+        want = slots * per_slot + (max(8, min(24, slots // 8)) if slots >= 32 else min(slots, 4)) * per_field + fixed + pools
         # the allocator rounds every block up (2 MiB granules): the estimate must not be below 90 % nor above 103 % of the truth
         assert 0.90 * used <= want <= 1.03 * used + (64 << 20), (slots, used, want)
         s.close()
