@@ -84,8 +84,13 @@ struct wa_acs {
     int32_t n_slots, max_colony, n_active, nb;
     int64_t path_cap;
     WaAcsDev D;            // D.pher always points at the CURRENT pheromone buffer
-    int32_t *d_stage = nullptr;      // staging block of wa_acs_result_batch (the best paths of all slots, packed), grows on demand
+    int32_t *d_stage = nullptr;      // staging block of acs_fetch_results (the best paths of all slots, packed), grows on demand
     size_t stage_words = 0;
+    // host copy of every slot's control block and best path behind the last run (acs_fetch_results): wa_acs_result / _batch read it
+    std::vector<WaSlotCtl> res_ctl;
+    std::vector<int32_t> res_words;
+    int64_t res_longest = 0;
+    bool res_valid = false;
     int32_t *paths_arr[2] = {nullptr, nullptr};   // the ants' paths: one array ([1] == [0]), or two alternating by generation when stragglers are handed over
     float *pher_buf[2];    // double buffer: evaporation writes the other one (dst = src * rho)
     float *pher_alloc[2], *heur_alloc;   // the allocations behind pher_buf[] / D.heur (fields + guard bands)
