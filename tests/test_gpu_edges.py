@@ -419,3 +419,38 @@ def test_straggler_hand_over_across_run_boundaries(ctx, chunks, nb):
     assert np.array_equal(bits(s.pheromone()), bits(a.pheromone()))
     s.close()
     dg.close()
+
+
+def test_results_read_between_runs_and_between_problems_are_never_stale(ctx):
+    """wa_acs_result / wa_acs_result_batch serve a host copy fetched once behind a run (host_acs.inc: acs_fetch_results): it has to be
+    dropped by the next wa_acs_run and the next wa_acs_begin.  Read after every 3 generations of a 24-generation search in 4 slots, per
+    slot and as a batch, against the oracle's state at that generation; then another problem on the same solver."""
+    og = box_grid(14, 12, 10, occ_prob=0.12, seed=5)
+    free_ids = np.flatnonzero(og.free)
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    s = api.AcsSolver(ctx, dg, 4, 24)
+    starts = [int(free_ids[3]), int(free_ids[11]), int(free_ids[40]), int(free_ids[7])]
+    ends = [int(free_ids[-5]), int(free_ids[-40]), int(free_ids[-9]), int(free_ids[-77])]
+    for round_ in range(2):
+        if round_:
+            starts, ends = ends[::-1], starts[::-1]
+        p = api.default_params(max_iteration=24, predict=40.0, fixed_colony=24, rng_mode=api.RNG_DEV, seed=11 + round_)
+        s.init_pheromone(1.0)
+        s.begin(p, starts, ends, streams=[0, 1, 2, 3])
+        changed = 0
+        last = [None] * 4
+        for g in range(0, 24, 3):
+            s.run(3)
+            costs, paths = s.results()
+            for q in range(4):
+                a = O.Acs(og)
+                a.solve(starts[q], ends[q], g + 3, 40.0, fixed_colony=24, mode=O.DEV, seed=11 + round_, stream=q)
+                cost, path, ch = s.result(q)
+                assert bits(cost) == bits(a.best_L) == bits(costs[q])
+                if np.isfinite(cost):
+                    assert np.array_equal(path, a.best_path()[0]) and np.array_equal(ch.astype(np.int32), a.best_path()[1])
+                    assert np.array_equal(paths[q], path)
+                if last[q] is not None and bits(cost) != bits(last[q]):
+                    changed += 1
+                last[q] = cost
+        assert changed > 0      # the best cost did move between reads: a stale copy would have been caught
