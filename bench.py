@@ -386,7 +386,7 @@ def c5_full_extra(ctx):
     runs = []
     for rep in range(2):
         # first: the solver is built from what the context kept of the earlier extras' solvers (other shapes: the arena re-maps their chunks)
-        # plus fresh memory, which the driver zero-fills when it is allocated (~25-40 ms per GB: that, not the library, is the first creation);
+        # plus fresh memory, which the driver wipes first when an earlier process has used it (~25-40 ms per GB: that, not the library, is the first creation);
         # second: the same job again, as a planning service (or the drop-in, which creates its solver per searchBestPathOfPoints call) pays it
         st0 = ctx.cache_stats()
         t0 = time.perf_counter()
@@ -413,7 +413,7 @@ def c5_full_extra(ctx):
             "t_pairs_first_s": runs[0]["t_pairs_s"], "t_solver_create_first_s": runs[0]["t_solver_create_s"],
             "cache": {"arena": bool(ctx.cache_stats()["arena"]), "first": runs[0], "second": runs[1],
                       "note": "t_solver_create_s / t_pairs_s: the job run a second time on the same context (every block served from kept memory); *_first_s: the first "
-                              "time, behind the other extras' solvers -- cache_miss_gib of it is fresh device memory, which the driver zero-fills at allocation"},
+                              "time, behind the other extras' solvers -- cache_miss_gib of it is fresh device memory, which the driver wipes before handing it out if an earlier process on the box has used it"},
             "identical_costs_both_times": same,
             "t_gtsp_s": t_gtsp, "t_host_inputs_s": t_inputs, "t_memory_wait_s": waited, "pair_generations_per_s": pairs * gens / warm["t_pairs_s"],
             "all_reached": bool(np.isfinite(cost).all()), "tour_cost": float(tour["L"][0]), "tour_iterations": int(tour["iters"][0])}

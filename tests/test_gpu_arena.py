@@ -66,7 +66,7 @@ def test_solvers_of_other_shapes_feed_a_c5_sized_solver_on_poisoned_memory():
     assert mid["oom_events"] == before["oom_events"] == 0        # nothing had to be released to the driver to make room ...
     assert mid["released_bytes"] == 0
     assert mid["hit_bytes"] - before["hit_bytes"] > 0.8 * kept_small   # ... and what was kept was USED, whatever shape it came from
-    # what the kept chunks do not cover is created fresh, and the driver zero-fills fresh device memory when it is allocated (~25-40 ms
+    # what the kept chunks do not cover is created fresh, and the driver wipes device memory that earlier processes have used before handing it out (~25-40 ms
     # per GB on MI355X / ROCm 7.2, hipMalloc and hipMemCreate alike: profiles/r05/vmm_probe.txt) -- that, not the arena, is this time.
     # (Round 4: out of memory beside the kept blocks, everything released, then the wipe of ALL of it.)
     fresh_gib = (mid["miss_bytes"] - before["miss_bytes"]) / GiB

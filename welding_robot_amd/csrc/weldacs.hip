@@ -180,8 +180,9 @@ static int env_int(const char *name, int def)
 }
 
 // ------------------------------------------------------------------ the contexts' memory: an arena of physical chunks + a small block cache
-// Solvers take their device memory through ctx_alloc / ctx_free.  What a solver gives back STAYS with the context: the driver zero-fills
-// device memory when it is allocated and wipes it when it is released, at ~25-40 ms per GB (MI355X, ROCm 7.2), and the next allocation of
+// Solvers take their device memory through ctx_alloc / ctx_free.  What a solver gives back STAYS with the context: the driver wipes
+// device memory a process has used -- when it is released, and before the pages are handed out again -- at ~25-40 ms per GB (MI355X,
+// ROCm 7.2; untouched memory of a fresh box comes at once: profiles/r05/vmm_threads.txt), and the next allocation of
 // any size -- in this process or the next -- waits until all of it is clean: 3.9 s behind 64 GiB, 5.3 s behind the 190 GB of a C5-sized
 // solver, against the 0.1 s it takes to clear and initialise them (profiles/r04/alloc_after_free.txt, profiles/r05/vmm_probe.txt).
 //
