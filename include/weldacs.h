@@ -31,7 +31,7 @@ typedef enum {
     WA_ERR_DEVICE = 2,    /* no HIP device, HIP runtime error                            */
     WA_ERR_ALLOC = 3,     /* host or device allocation failed                            */
     WA_ERR_FILE = 4,      /* cannot open / short read (read_STL.hpp:34-59 exit(1..3))    */
-    WA_ERR_FORMAT = 5,    /* malformed STL / unsupported ASCII STL          */
+    WA_ERR_FORMAT = 5,    /* an ASCII STL the reference's reader never returns from     */
     WA_ERR_POINT = 6,     /* a route point resolves to no free voxel (ACSRank_3D.hpp:491) */
     WA_ERR_CAPACITY = 7,  /* a walk outgrew path_capacity / more ants than max_colony     */
     WA_ERR_STATE = 8      /* call order (e.g. results before a solve)                     */
@@ -79,7 +79,10 @@ void *wa_ctx_stream(wa_ctx *ctx);
 
 /* ---- mesh input: replaces STLReader::readFile + TriangleList (read_STL.hpp:26-77,:88,:131-156)
  * tris = n x 12 floats (normal, v0, v1, v2).  Returns the triangle count (>= 0) or -wa_status.
- * Pass tris = NULL to query the count. */
+ * Pass tris = NULL to query the count.  Byte 79 != 0 selects the ASCII branch (:65-68, :99-129), read with the reference's stream
+ * semantics: normals stay (0, 0, 0), an unreadable vertex keeps the previous triangle's value, a text without a
+ * "facet" word where the reader expects one gives 0 triangles.  WA_ERR_FORMAT: the text ends directly behind a "facet" word (the
+ * reference's loop does not end on it); WA_ERR_FILE: shorter than the 80 bytes the sniff reads / a truncated binary file. */
 int64_t wa_stl_parse(const void *buf, size_t len, float *tris, int64_t cap_tris);
 int64_t wa_stl_read_file(const char *path, float *tris, int64_t cap_tris);
 

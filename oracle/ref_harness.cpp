@@ -20,6 +20,7 @@
 // Sub-commands (key=value arguments):
 //   rand      seed= n=                         glibc rand() known answers
 //   sort      n= seed= levels=                 std::sort permutation on tied float keys
+//   stl       stl=                             STLReader::readFile alone (binary or ASCII): n_tris + the triangle list
 //   voxelize  stl= p= wall= [gridout=]         STLReader + GridMap::creatGridMap
 //   acs       (stl= p= wall= | gridin=) (snode=z,y,x enode=z,y,x | spt=x,y,z ept=x,y,z)
 //             seed= iters= predict= [driven=0|1] [fixed=N] [dumppher=1] [nb=6|26]
@@ -339,6 +340,21 @@ static int cmd_sort(const Args &a, Waf &w)
     for (int i = 0; i < n; i++) perm[i] = v[i].tag;
     w.f32("keys", keys);
     w.i32("perm", perm);
+    return 0;
+}
+
+static int cmd_stl(const Args &a, Waf &w)
+{
+    STLReader model;
+    model.readFile(gets(a, "stl"));
+    w.one_i64("n_tris", (int64_t)model.TriangleList().size());
+    w.one_i64("num_tri", (int64_t)model.NumTri());
+    std::vector<float> tris;
+    for (auto &t : model.TriangleList()) {
+        tris.push_back(t.nor_vec.x); tris.push_back(t.nor_vec.y); tris.push_back(t.nor_vec.z);
+        for (int j = 0; j < 3; j++) { tris.push_back(t.vertex[j].x); tris.push_back(t.vertex[j].y); tris.push_back(t.vertex[j].z); }
+    }
+    w.f32("tris", tris);
     return 0;
 }
 
@@ -673,7 +689,7 @@ static void smooth_like_main(Waf &w, ACS_GTSP &g, uint32_t fill_bits)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness <rand|sort|voxelize|acs|pairs|gtsp|bspline> key=value...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness <rand|sort|stl|voxelize|acs|pairs|gtsp|bspline> key=value...\n"); return 2; }
     Args a = parse(argc, argv);
     if (!has(a, "out")) { fprintf(stderr, "out=FILE required\n"); return 2; }
     // the reference narrates every generation / distance on stdout: silence it
@@ -682,6 +698,7 @@ int main(int argc, char **argv)
     std::string c(argv[1]);
     if (c == "rand") return cmd_rand(a, w);
     if (c == "sort") return cmd_sort(a, w);
+    if (c == "stl") return cmd_stl(a, w);
     if (c == "voxelize") return cmd_voxelize(a, w);
     if (c == "acs") return cmd_acs(a, w);
     if (c == "pairs") return cmd_pairs(a, w);

@@ -13,6 +13,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include "weld_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -226,12 +227,148 @@ void wo_stable_rank_perm(const float *keys, int32_t n, int32_t *perm)
 }
 
 /* ================================================================== STL ============ */
-/* read_STL.hpp:65-72 format sniff on byte 79, :131-156 binary layout.  The reference
- * exit()s on I/O errors (:34-59); the restatement returns negative codes instead. */
+/* read_STL.hpp:65-72 format sniff on byte 79, :131-156 binary layout, :99-129 the ASCII branch.  The reference
+ * exit()s on I/O errors (:34-59); the restatement returns negative codes instead.
+ *
+ * ASCII (:99-129): the reference wraps the file in a std::stringstream (the text up to the first NUL byte) and reads
+ *   ss >> name >> name; ss.get();
+ *   loop { ss >> w; if (w != "facet") break; getline x 2; 3 x (ss >> w >> x >> y >> z); push; getline x 3; }
+ * with ONE Triangles object declared outside the loop: the "facet normal ..." line is skipped, so every normal stays (0, 0, 0)
+ * (plane distance 0 => every voxel of a triangle's bounding box +- p is occupied), and a read that fails leaves the
+ * previous triangle's values in place.  Restated with the stream semantics of libstdc++ (GCC 11): sentry / skipws, eofbit and
+ * failbit, operator>>(string) leaving its target alone when the sentry fails, num_get's character filter (bits/locale_facets.tcc
+ * _M_extract_float, "C" locale) in front of strtof, value 0 + failbit on a conversion error, +-FLT_MAX + failbit on overflow.
+ * One input the reference never returns from -- the text ends directly behind a "facet" token, so that every later read fails
+ * with "facet" still in the string: an endless push_back -- is reported as -10. */
+typedef struct { const uint8_t *s; size_t n, pos; int eof, fail; } wo_is;
+static int wo_is_space(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+static int wo_is_sentry(wo_is *t, int noskipws)
+{
+    int good = !t->eof && !t->fail;
+    if (good && !noskipws) {
+        while (t->pos < t->n && wo_is_space(t->s[t->pos])) t->pos++;
+        if (t->pos >= t->n) { t->eof = 1; good = 0; }
+    }
+    if (good) return 1;
+    t->fail = 1;
+    return 0;
+}
+/* operator>>(istream&, string&): 1 = the string was assigned [*tok, *tok + *len) */
+static int wo_is_token(wo_is *t, const uint8_t **tok, size_t *len)
+{
+    if (!wo_is_sentry(t, 0)) return 0;
+    const size_t a = t->pos;
+    while (t->pos < t->n && !wo_is_space(t->s[t->pos])) t->pos++;
+    if (t->pos >= t->n) t->eof = 1;
+    *tok = t->s + a;
+    *len = t->pos - a;
+    if (*len == 0) t->fail = 1;
+    return 1;
+}
+/* std::getline(istream&, string&): 1 = the string was assigned */
+static int wo_is_getline(wo_is *t, const uint8_t **line, size_t *len)
+{
+    if (!wo_is_sentry(t, 1)) return 0;
+    const size_t a = t->pos;
+    size_t extracted = 0;
+    while (t->pos < t->n && t->s[t->pos] != '\n') { t->pos++; extracted++; }
+    *line = t->s + a;
+    *len = t->pos - a;
+    if (t->pos >= t->n) t->eof = 1;
+    else { t->pos++; extracted++; }
+    if (!extracted) t->fail = 1;
+    return 1;
+}
+static void wo_is_get(wo_is *t)
+{
+    if (!wo_is_sentry(t, 1)) return;
+    if (t->pos < t->n) t->pos++;
+    else { t->eof = 1; t->fail = 1; }
+}
+/* operator>>(istream&, float&) */
+static void wo_is_float(wo_is *t, float *v)
+{
+    if (!wo_is_sentry(t, 0)) return;
+    char x[512];
+    size_t k = 0;
+    int eof = t->pos >= t->n, mant = 0, dec = 0, sci = 0;
+    int c = eof ? 0 : t->s[t->pos];
+#define WO_NEXT() do { if (++t->pos < t->n) c = t->s[t->pos]; else eof = 1; } while (0)
+#define WO_PUT(ch) do { if (k + 1 < sizeof x) x[k++] = (char)(ch); } while (0)
+    if (!eof && (c == '+' || c == '-')) { WO_PUT(c); WO_NEXT(); }
+    while (!eof && c == '0') {              /* leading zeros collapse into one */
+        if (!mant) { WO_PUT('0'); mant = 1; }
+        WO_NEXT();
+    }
+    while (!eof) {
+        if (c >= '0' && c <= '9') { WO_PUT(c); mant = 1; }
+        else if (c == '.' && !dec && !sci) { WO_PUT('.'); dec = 1; }
+        else if ((c == 'e' || c == 'E') && !sci && mant) {
+            WO_PUT('e');
+            sci = 1;
+            if (++t->pos < t->n) {
+                c = t->s[t->pos];
+                if (c == '+' || c == '-') WO_PUT(c);
+                else continue;
+            } else { eof = 1; break; }
+        } else break;
+        WO_NEXT();
+    }
+#undef WO_NEXT
+#undef WO_PUT
+    x[k] = 0;
+    char *end = x;
+    float r = strtof(x, &end);
+    if (end == x || *end != 0) { r = 0.f; t->fail = 1; }
+    else if (r == INFINITY) { r = FLT_MAX; t->fail = 1; }
+    else if (r == -INFINITY) { r = -FLT_MAX; t->fail = 1; }
+    *v = r;
+    if (eof) t->eof = 1;
+}
+static int wo_tok_is(const uint8_t *p, size_t len, const char *w) { return len == strlen(w) && memcmp(p, w, len) == 0; }
+/* tris == NULL: count only */
+static int64_t wo_stl_ascii(const uint8_t *buf, size_t len, float *tris)
+{
+    wo_is t = {buf, 0, 0, 0, 0};
+    while (t.n < len && buf[t.n] != 0) t.n++;      /* std::stringstream ss(buffer): a C string */
+    const uint8_t *w = (const uint8_t *)"";
+    size_t wl = 0;
+    const uint8_t *q;
+    size_t ql;
+    if (wo_is_token(&t, &q, &ql)) { w = q; wl = ql; }
+    if (wo_is_token(&t, &q, &ql)) { w = q; wl = ql; }   /* (into `name`, not `useless`: kept apart below) */
+    wo_is_get(&t);
+    w = (const uint8_t *)"";
+    wl = 0;
+    float tri[12];
+    memset(tri, 0, sizeof tri);
+    int64_t n = 0;
+    for (;;) {
+        const int got = wo_is_token(&t, &q, &ql);
+        if (got) { w = q; wl = ql; }
+        if (!wo_tok_is(w, wl, "facet")) break;
+        if (!got) return -10;                              /* nothing will ever change `useless` again: the reference loops forever */
+        if (wo_is_getline(&t, &q, &ql)) { w = q; wl = ql; }
+        if (wo_is_getline(&t, &q, &ql)) { w = q; wl = ql; }
+        for (int i = 0; i < 3; i++) {
+            if (wo_is_token(&t, &q, &ql)) { w = q; wl = ql; }
+            wo_is_float(&t, &tri[3 + 3 * i]);
+            wo_is_float(&t, &tri[4 + 3 * i]);
+            wo_is_float(&t, &tri[5 + 3 * i]);
+        }
+        if (tris) memcpy(tris + n * 12, tri, sizeof tri);
+        n++;
+        if (wo_is_getline(&t, &q, &ql)) { w = q; wl = ql; }
+        if (wo_is_getline(&t, &q, &ql)) { w = q; wl = ql; }
+        if (wo_is_getline(&t, &q, &ql)) { w = q; wl = ql; }
+    }
+    return n;
+}
 int64_t wo_stl_count(const uint8_t *buf, size_t len)
 {
+    if (len < 80) return -3;
+    if (buf[79] != 0) return wo_stl_ascii(buf, len, NULL);   /* :65-68 */
     if (len < 84) return -3;
-    if (buf[79] != 0) return -10; /* ASCII branch (:99-129) never fills normals (Q11): unsupported */
     int32_t n;
     memcpy(&n, buf + 80, 4);
     if (n < 0 || (size_t)n * 50 + 84 > len) return -3;
@@ -241,6 +378,7 @@ int64_t wo_stl_parse(const uint8_t *buf, size_t len, float *tris)
 {
     int64_t n = wo_stl_count(buf, len);
     if (n < 0) return n;
+    if (buf[79] != 0) return wo_stl_ascii(buf, len, tris);
     const uint8_t *p = buf + 84;
     for (int64_t i = 0; i < n; i++) {
         memcpy(tris + i * 12, p, 48); /* normal, v0, v1, v2 (:142-150) */

@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle_lib as O  # noqa: E402
 import waf  # noqa: E402
+from stl_text import ascii_stl_text, ascii_stl_variants  # noqa: E402,F401
 
 REFROOT = "/root/reference"
 TMP = "/tmp/weld_golden"
@@ -155,6 +156,47 @@ def gen_nb26():
     print("synth64 nb26", a["best_L"], a["tr_steps"], a["tr_finite"])
 
 
+def gen_ascii():
+    """SURVEY 8(a) a1, the ASCII branch of STLReader (read_STL.hpp:99-129): files made HERE from cubic.stl's twelve triangles,
+    read by the reference's own reader (harness command `stl`), plus the reference's voxelisation of the standard one (Q11: normals
+    stay 0, so every voxel of a triangle's bounding box +- p is occupied)."""
+    cubic = O.stl_parse(open(os.path.join(HERE, "cubic.stl"), "rb").read())
+    out = {}
+    tags = []
+    for tag, data in ascii_stl_variants(cubic, open(os.path.join(HERE, "cubic.stl"), "rb").read()):
+        f = TMP + "/ascii_%s.stl" % tag
+        open(f, "wb").write(data)
+        r = O.run_ref("stl", TMP + "/s.waf", stl=f)
+        out["file_" + tag] = np.frombuffer(data, np.uint8).copy()
+        out["n_" + tag] = r["n_tris"]
+        out["tris_" + tag] = np.asarray(r["tris"], np.float32)
+        tags.append(tag)
+        print("%-30s %5d bytes -> %3d triangles" % (tag, len(data), int(np.asarray(r["n_tris"]).reshape(-1)[0])))
+    out["tags"] = np.frombuffer(" ".join(tags).encode(), np.uint8).copy()
+    waf.save(HERE + "/stl_ascii.waf", out)
+    f = os.path.join(HERE, "cubic_ascii.stl")
+    open(f, "wb").write(ascii_stl_text(cubic))
+    v = O.run_ref("voxelize", TMP + "/va.waf", stl=f, p="0.0219", wall=8)
+    v = pack_free(v)
+    v.pop("t_voxelize", None)
+    waf.save(HERE + "/vox_cubic_ascii_p0219_w8.waf", v)
+    print("vox_cubic_ascii_p0219_w8: dims %s, %d free" % (v["dims"][:3].tolist(), int(np.unpackbits(v["free_packed"]).sum())))
+    # the work piece as text (5 977 triangles that are NOT axis-aligned: with the normals gone the occupancy differs from the binary file's)
+    piece = O.stl_parse(open(os.path.join(HERE, "simplified_piece.stl"), "rb").read())
+    f = TMP + "/piece_ascii.stl"
+    open(f, "wb").write(ascii_stl_text(piece, name="piece"))
+    v = O.run_ref("voxelize", TMP + "/vp.waf", stl=f, p="0.0148", wall=4)
+    v = pack_free(v)
+    v["tris_head"] = v["tris"][:12 * 16].copy()
+    v["tris_sum"] = np.array([np.sum(v["tris"].astype(np.float64))])
+    del v["tris"]
+    v.pop("t_voxelize", None)
+    waf.save(HERE + "/vox_piece_ascii_p0148_w4.waf", v)
+    b = waf.load(HERE + "/vox_piece_p0148_w4.waf")
+    print("vox_piece_ascii_p0148_w4: dims %s, %d free (the binary file: %d free)" % (v["dims"][:3].tolist(), int(np.unpackbits(v["free_packed"]).sum()),
+                                                                                  int(np.unpackbits(b["free_packed"]).sum())))
+
+
 def gen_origin():
     """The reference's largest mesh (files/origin_piece.stl, 29 888 triangles: the un-simplified work piece SURVEY 8(f) N1 quotes) voxelised
     by the reference's creatGridMap at precision 0.0100, wall 4 (91 x 45 x 30 voxels: ~30 s of the reference's O(T N^3) loop)."""
@@ -194,6 +236,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "origin":
         gen_origin()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ascii":
+        gen_ascii()
         return
     for f in ("cubic.stl", "simplified_piece.stl"):
         shutil.copyfile(os.path.join(REFROOT, "files", f), os.path.join(HERE, f))

@@ -75,14 +75,67 @@ def test_stl_parse_matches_oracle(lib):
         assert np.array_equal(api.stl_read_file(os.path.join(G, f)).view(np.uint32), b.view(np.uint32))
 
 
+def test_stl_ascii_reader_matches_the_reference_and_the_oracle(lib):
+    """the ASCII branch (read_STL.hpp:99-129) through the C ABI: the committed text files against what the reference's own reader
+    returned for them (tests/golden/stl_ascii.waf, made by make_golden.py ascii), and damaged files against the oracle"""
+    import stl_text
+    import waf
+    g = waf.load(os.path.join(G, "stl_ascii.waf"))
+    for tag in bytes(g["tags"]).decode().split():
+        t = api.stl_parse(bytes(g["file_" + tag]))
+        ref = np.asarray(g["tris_" + tag], np.float32).reshape(-1, 12)
+        assert t.shape == ref.shape and np.array_equal(t.view(np.uint32), ref.view(np.uint32)), tag
+    t = api.stl_read_file(os.path.join(G, "cubic_ascii.stl"))
+    assert np.array_equal(t.view(np.uint32), np.asarray(g["tris_standard"], np.float32).reshape(-1, 12).view(np.uint32))
+    rs = np.random.RandomState(3)
+    piece = O.stl_parse(open(os.path.join(G, "simplified_piece.stl"), "rb").read())
+    text = stl_text.ascii_stl_text(piece[:40], name="piece")
+    junk = [b"facet", b"vertex", b"endsolid", b"1e", b".", b"-", b"+.e1", b"0x10", b"inf", b"nan", b"1e400", b"-1e-400", b"12abc", b"\n", b"\r\n", b"\v"]
+    refused = 0
+    for case in range(300):
+        toks = text.replace(b"\n", b" \n ").split(b" ")
+        for _ in range(int(rs.randint(1, 8))):
+            k = int(rs.randint(0, len(toks)))
+            what = int(rs.randint(0, 4))
+            if what == 0:
+                del toks[k]
+            elif what == 1:
+                toks[k] = junk[int(rs.randint(0, len(junk)))]
+            elif what == 2:
+                toks.insert(k, junk[int(rs.randint(0, len(junk)))])
+            else:
+                del toks[k:k + int(rs.randint(1, 60))]
+        data = b" ".join(toks)
+        if case % 3 == 0:
+            data = data[:int(rs.randint(80, len(data)))]
+        data = data.ljust(81, b" ")
+        try:
+            want = O.stl_parse(data)
+        except ValueError:
+            want = None
+        if want is None:
+            with pytest.raises(api.WeldacsError):
+                api.stl_parse(data)
+            refused += 1
+            continue
+        got = api.stl_parse(data)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, data)
+    # capacity: a count query, then a buffer that is too small
+    n = lib.wa_stl_parse(text, len(text), None, 0)
+    assert n == 40
+    small = np.empty((39, 12), np.float32)
+    assert lib.wa_stl_parse(text, len(text), small.ctypes.data_as(C.c_void_p), 39) == -7   # WA_ERR_CAPACITY
+
+
 def test_stl_error_codes(lib):
     data = bytearray(open(os.path.join(G, "cubic.stl"), "rb").read())
     with pytest.raises(api.WeldacsError) as e:
         api.stl_parse(bytes(data[:100]))
     assert e.value.code == 4  # short read -> the reference exit(3)s (read_STL.hpp:55-59)
     data[79] = ord("s")
+    assert api.stl_parse(bytes(data)).shape == (0, 12)   # sniffed as ASCII (read_STL.hpp:65): the text holds no "facet"
     with pytest.raises(api.WeldacsError) as e:
-        api.stl_parse(bytes(data))
+        api.stl_parse(b"solid s\n" + b" " * 80 + b"facet")   # the reference's loop never ends on this text (:107-126)
     assert e.value.code == 5
     with pytest.raises(api.WeldacsError) as e:
         api.stl_read_file("/nonexistent/file.stl")

@@ -30,8 +30,8 @@ def compile_demo():
     return EXE
 
 
-def run_demo(mode, seed, out):
-    args = [EXE, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5",
+def run_demo(mode, seed, out, stl="cubic.stl"):
+    args = [EXE, os.path.join(G, stl), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5",
             out + ".graph", mode, str(seed), out]
     return subprocess.run(args, capture_output=True, text=True)
 
@@ -69,10 +69,17 @@ def test_dropin_headers_compile_with_host_compiler_and_need_a_gpu():
 
 
 @pytest.mark.gpu
-def test_dropin_pipeline_ref_mode_equals_reference():
+@pytest.mark.parametrize("stl", ["cubic.stl", "cubic_ascii.stl"])
+def test_dropin_pipeline_ref_mode_equals_reference(stl):
+    """(cubic_ascii.stl: the same twelve triangles as text, through the ASCII branch of STLReader::readFile, read_STL.hpp:99-129.  Its
+    normals stay 0 -- but the cube's faces are axis-aligned, so the reference's grid is the same one (the two goldens below), and with
+    it every number of the pipeline.)"""
+    if stl != "cubic.stl":
+        a, b = waf.load(os.path.join(G, "vox_cubic_ascii_p0219_w8.waf")), waf.load(os.path.join(G, "vox_cubic_p0219_w8.waf"))
+        assert all(np.array_equal(a[k], b[k]) for k in ("dims", "cx", "cy", "cz", "free_packed"))
     compile_demo()
     out = "/tmp/weldacs_dropin_ref.txt"
-    r = run_demo("ref", 4321, out)
+    r = run_demo("ref", 4321, out, stl)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = parse(out)
     g = waf.load(os.path.join(G, "pairs_cubic.waf"))

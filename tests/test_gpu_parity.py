@@ -71,6 +71,26 @@ def test_voxelize_matches_reference(ctx, tag, stl, p, wall):
         assert O.fnv1a_bytes(occ.tobytes()) == 0x5A60BC32E3EFED2F and dg.n_free == 17732  # KA1
 
 
+@pytest.mark.parametrize("tag,src,p,wall,name", [("cubic_ascii_p0219_w8", "cubic.stl", "0.0219", 8, "cubic"),
+                                                 ("piece_ascii_p0148_w4", "simplified_piece.stl", "0.0148", 4, "piece")])
+def test_voxelize_ascii_stl_matches_reference(ctx, tag, src, p, wall, name):
+    """the ASCII branch of STLReader (read_STL.hpp:99-129) in front of creatGridMap: the text form of the mesh, read by wa_stl_parse
+    (normals stay 0) and voxelised on the device, against the reference's own run on the same text"""
+    import stl_text
+    g = _g("vox_%s.waf" % tag)
+    text = stl_text.ascii_stl_text(api.stl_read_file(os.path.join(G, src)), name=name)
+    tris = api.stl_parse(text)
+    assert not tris[:, :3].any()
+    dg = api.Grid.from_mesh(ctx, tris, float(p), wall)
+    assert [dg.nx, dg.ny, dg.nz, dg.wall] == g["dims"].tolist()
+    cx, cy, cz = dg.coords()
+    assert np.array_equal(bits(cx), bits(g["cx"])) and np.array_equal(bits(cy), bits(g["cy"])) and np.array_equal(bits(cz), bits(g["cz"]))
+    occ = dg.occupancy()
+    assert np.array_equal(np.packbits(occ), g["free_packed"])
+    if name == "piece":
+        assert dg.n_free == 43747          # the binary file: 45 086
+
+
 def test_voxelize_random_mesh_vs_oracle(ctx):
     rs = np.random.RandomState(5)
     tris = np.zeros((40, 12), np.float32)

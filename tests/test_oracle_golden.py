@@ -88,8 +88,53 @@ def test_stl_errors():
     with pytest.raises(ValueError):
         O.stl_parse(bytes(data[:200]))  # truncated
     data[79] = ord("x")
+    assert O.stl_parse(bytes(data)).shape == (0, 12)  # ASCII sniff (read_STL.hpp:65): read as text, which finds no "facet"
     with pytest.raises(ValueError):
-        O.stl_parse(bytes(data))  # ASCII sniff (read_STL.hpp:65)
+        O.stl_parse(b"solid s\n" + b" " * 80 + b"facet")   # ends behind a "facet" token: the reference's loop never ends (:107-126)
+
+
+def test_stl_ascii_reader_golden():
+    """read_STL.hpp:99-129 on text files made from cubic.stl's triangles -- well-formed ones and the malformed ones that show the
+    reader's stream semantics (tests/stl_text.py) -- against what the reference's own reader returned (harness command `stl`)."""
+    import stl_text
+    g = _g("stl_ascii.waf")
+    made = dict(stl_text.ascii_stl_variants(_mesh("cubic.stl"), open(os.path.join(G, "cubic.stl"), "rb").read()))
+    tags = bytes(g["tags"]).decode().split()
+    assert sorted(tags) == sorted(made)
+    seen = set()
+    for tag in tags:
+        data = bytes(g["file_" + tag])
+        assert data == made[tag], tag                           # the committed inputs are what the generator makes
+        t = O.stl_parse(data)
+        ref = np.asarray(g["tris_" + tag], np.float32).reshape(-1, 12)
+        assert t.shape == ref.shape == (waf.scalar(g, "n_" + tag), 12), tag
+        assert np.array_equal(bits(t), bits(ref)), tag
+        assert not t[:, :3].any()                               # Q11: the ASCII branch never reads a normal
+        seen.add(len(t))
+    assert {0, 2, 3, 12} <= seen
+    std = O.stl_parse(bytes(g["file_standard"]))
+    assert np.array_equal(bits(std[:, 3:]), bits(_mesh("cubic.stl")[:, 3:]))   # %.9g text round-trips the vertices exactly
+
+
+@pytest.mark.parametrize("tag,src,p,wall,name", [("cubic_ascii_p0219_w8", "cubic.stl", "0.0219", 8, "cubic"),
+                                                 ("piece_ascii_p0148_w4", "simplified_piece.stl", "0.0148", 4, "piece")])
+def test_voxelize_ascii_golden(tag, src, p, wall, name):
+    """... and the reference's voxelisation of such a file: with all normals 0 the plane distance is 0 and every voxel of a triangle's
+    bounding box +- p is occupied; on the work piece that is 1 339 voxels more than the binary file gives."""
+    import stl_text
+    g = _g("vox_%s.waf" % tag)
+    t = O.stl_parse(stl_text.ascii_stl_text(_mesh(src), name=name))
+    if "tris" in g:
+        assert np.array_equal(bits(t.reshape(-1)), bits(g["tris"]))
+    else:
+        assert np.array_equal(bits(t.reshape(-1)[:192]), bits(g["tris_head"])) and float(np.sum(t.astype(np.float64))) == waf.scalar(g, "tris_sum")
+    grid = O.grid_from_mesh(t, float(p), wall)
+    assert [grid.nx, grid.ny, grid.nz, wall] == g["dims"].tolist()
+    for ax in ("cx", "cy", "cz"):
+        assert np.array_equal(bits(getattr(grid, ax)), bits(g[ax])), ax
+    assert np.array_equal(np.packbits(grid.free), g["free_packed"])
+    if src == "simplified_piece.stl":
+        assert int(grid.free.sum()) == 43747 and int(_grid(src, p, wall).free.sum()) == 45086
 
 
 @pytest.mark.parametrize("tag,stl,p,wall", [("cubic_p0219_w8", "cubic.stl", "0.0219", 8),

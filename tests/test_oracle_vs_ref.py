@@ -119,3 +119,55 @@ def test_splines_random():
         for k in range(d + 2):
             out, ok = b.eval(g["u"], k)
             assert np.array_equal(ok, g["ok%d" % k]) and np.array_equal(bits(out), bits(g["der%d" % k])), (i, d, ci, cf, n, k)
+
+
+def test_ascii_stl_reader_on_mutated_files():
+    """read_STL.hpp:99-129 against the oracle's restatement on text files with random damage: tokens dropped, swapped, replaced by
+    junk, lines cut, numbers respelt.  Every file ends in a NUL byte (the reference reads on past the end of its buffer otherwise).
+    A file on which the reference's loop does not end (it ends behind a "facet" token) must be the one the oracle refuses."""
+    import subprocess
+    import stl_text
+    rs = np.random.RandomState(77)
+    cubic = O.stl_parse(open(os.path.join(G, "cubic.stl"), "rb").read())
+    std = stl_text.ascii_stl_text(cubic[:5])
+    junk = [b"facet", b"vertex", b"endsolid", b"1e", b".", b"-", b"+.e1", b"0x10", b"inf", b"1e400", b"-1e-400", b"12abc", b"\t", b"\n", b"\r\n", b"\v", b" "]
+    n_cmp = n_refused = 0
+    for case in range(120):
+        toks = std.replace(b"\n", b" \n ").split(b" ")
+        for _ in range(int(rs.randint(1, 6))):
+            k = int(rs.randint(0, len(toks)))
+            what = int(rs.randint(0, 4))
+            if what == 0:
+                del toks[k]
+            elif what == 1:
+                toks[k] = junk[int(rs.randint(0, len(junk)))]
+            elif what == 2:
+                toks.insert(k, junk[int(rs.randint(0, len(junk)))])
+            else:
+                del toks[k:k + int(rs.randint(1, 30))]
+        data = b" ".join(toks)
+        if rs.uniform() < 0.3:
+            data = data[:int(rs.randint(80, max(81, len(data))))]
+        data = data.ljust(81, b" ") + b"\0"
+        if case == 0:
+            data = b"solid s\n" + b" " * 80 + b"facet\0"      # the text ends behind a "facet" token
+        f = TMP + "/fuzz.stl"
+        open(f, "wb").write(data)
+        try:
+            mine = O.stl_parse(data)
+        except ValueError:
+            mine = None
+        try:
+            subprocess.check_call([O.REF_BIN, "stl", "out=%s" % (TMP + "/fz.waf"), "stl=%s" % f], stderr=subprocess.DEVNULL, timeout=5,
+                                  preexec_fn=lambda: __import__("resource").setrlimit(__import__("resource").RLIMIT_AS, (1 << 30, 1 << 30)))
+            r = waf.load(TMP + "/fz.waf")
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError):
+            assert mine is None, (case, data)       # the endless push_back: killed by the clock or by the address-space limit
+            n_refused += 1
+            continue
+        assert mine is not None, (case, data)
+        ref = np.asarray(r["tris"], np.float32).reshape(-1, 12)
+        assert mine.shape == ref.shape and np.array_equal(bits(mine), bits(ref)), (case, data)
+        n_cmp += 1
+    assert n_cmp >= 100 and n_refused >= 1
+    print("ascii stl fuzz: %d files equal, %d refused on both sides" % (n_cmp, n_refused))

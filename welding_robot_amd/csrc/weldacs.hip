@@ -7,6 +7,8 @@
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
+#include <float.h>
+#include <locale.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,8 +1,8 @@
 // read_STL.hpp -- drop-in for the reference's core/read_STL.hpp on the C ABI (wa_stl_read_file).
 // Same class and members (STLReader::readFile / NumTri / PointList / TriangleList).  The reference
 // exit(1..3)s on I/O errors (read_STL.hpp:34-59); this header prints the same message and returns
-// false instead -- a library must not end the process.  ASCII STL is refused: the reference's ASCII
-// branch never reads normals, which marks every voxel in each triangle's bbox occupied.
+// false instead -- a library must not end the process.  ASCII STL is read as the reference reads it
+// (:99-129: the normals stay 0, which marks every voxel in each triangle's bbox occupied).
 #ifndef _READ_STL_HPP
 #define _READ_STL_HPP
 #include <stdio.h>
@@ -20,7 +20,7 @@ public:
     {
         int64_t n = wa_stl_read_file(file_name.c_str(), NULL, 0);
         if (n < 0) {
-            fputs(n == -WA_ERR_FORMAT ? "ASCII STL is not supported" : (n == -WA_ERR_FILE ? "File error" : "Reading error"), stderr);
+            fputs(n == -WA_ERR_FORMAT ? "Format error" : (n == -WA_ERR_FILE ? "File error" : "Reading error"), stderr);
             return false;
         }
         std::vector<float> t((size_t)n * 12);
