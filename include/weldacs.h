@@ -206,7 +206,9 @@ int wa_acs_solve(wa_acs *s, const wa_acs_params *p, int32_t n_problems, const in
                  const int64_t *end_ids, const uint32_t *streams);
 
 /* best-so-far of a slot (Agent<float> best: L, path ids, edge choices = nodeIndex()).  When no
- * ant has arrived cost = +inf (a valid result) and len = 0. */
+ * ant has arrived cost = +inf (a valid result) and len = 0.  The first read behind a run (wa_acs_run / wa_acs_solve)
+ * fetches every slot's result to the host in one go; wa_acs_result / wa_acs_result_batch* are served from that copy until the next
+ * wa_acs_begin / wa_acs_run (a per-slot read in a host loop, getSolution :506-509, costs a host array access). */
 int wa_acs_result(wa_acs *s, int32_t slot, float *cost, int64_t *len, int32_t *path_ids,
                   int8_t *choices, int64_t cap);
 /* the same for slots 0 .. n_slots-1 in one round trip (batched pair searches): costs[q], lens[q] (0 when the cost is
