@@ -84,3 +84,28 @@ def test_every_tool_and_example_script_still_compiles():
                 mod = importlib.import_module(node.module)
                 for a in node.names:
                     assert hasattr(mod, a.name) or importlib.util.find_spec(node.module + "." + a.name), (f, node.module, a.name)
+
+
+def test_host_side_writes_to_device_blocks_are_stream_ordered():
+    """A block from the context's allocator may still have work queued on the context's (non-blocking) stream -- the 0xff fill of
+    WA_DEV_POISON=1, or whatever the previous owner of a recycled block left there.  A synchronous hipMemcpy / hipMemset runs on the null
+    stream and does not wait for it (round 5: the "L after i steps" table of acs_create was uploaded that way and, once in ~5 000 solvers
+    of the poisoned soak run, lost against the fill).  So: no synchronous host-to-device copy and no synchronous memset in the host code,
+    except where a synchronisation stands directly in front (the two counter resets of the debug read-outs)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "welding_robot_amd", "csrc")
+    allowed_memset = {"wa_acs_debug_counters", "wa_acs_straggler_counters"}
+    bad = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.inc")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        fn = None
+        for n, line in enumerate(open(f), 1):
+            m = re.match(r"^(?:static\s+)?(?:int|int64_t|void|hipError_t)\s+(\w+)\(", line)
+            if m:
+                fn = m.group(1)
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemcpy\(", code) and "HostToDevice" in code:
+                bad.append("%s:%d %s" % (os.path.basename(f), n, code.strip()))
+            if re.search(r"\bhipMemset\(", code) and fn not in allowed_memset:
+                bad.append("%s:%d %s" % (os.path.basename(f), n, code.strip()))
+    assert not bad, "\n".join(bad)
