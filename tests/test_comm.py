@@ -10,9 +10,10 @@ import pytest
 
 import oracle_lib as O
 from welding_robot_amd import _lib, api, build, synth
+from tmpw import TMPW
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = "/tmp/weldacs_multistart_%d" % os.getuid()
+EXE = TMPW + "weldacs_multistart_%d" % os.getuid()
 
 
 def bits(a):
@@ -40,7 +41,7 @@ def test_library_links_rccl_itself_and_the_cpp_host_compiles_without_torch():
     if lib.wa_ctx_create(0, C.byref(h)) == 0:
         lib.wa_ctx_destroy(h)
         pytest.skip("a HIP device is present")
-    r = subprocess.run([EXE, "16", "8", "4", "all", "/tmp/weldacs_ms_cpu.txt"], capture_output=True, text=True)
+    r = subprocess.run([EXE, "16", "8", "4", "all", TMPW + "weldacs_ms_cpu.txt"], capture_output=True, text=True)
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
 
 
@@ -188,7 +189,7 @@ def check_multistart(devices, env=None, want_ranks=None):
     """(also run by tests/test_gpu_mock_ranks.py with three ranks on one GPU, RCCL replaced by the mock)"""
     compile_multistart()
     n, ants, K = 48, 64, 60
-    out = "/tmp/weldacs_ms_%d.txt" % os.getpid()
+    out = TMPW + "weldacs_ms_%d.txt" % os.getpid()
     r = subprocess.run([EXE, str(n), str(ants), str(K), devices, out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout + r.stderr
     loc, glob, owner, owner_path = {}, {}, {}, None

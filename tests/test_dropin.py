@@ -11,10 +11,11 @@ import pytest
 
 import waf
 from welding_robot_amd import _lib, build
+from tmpw import TMPW
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-EXE = "/tmp/weldacs_dropin_demo_%d" % os.getuid()
+EXE = TMPW + "weldacs_dropin_demo_%d" % os.getuid()
 
 
 def compile_demo():
@@ -64,7 +65,7 @@ def test_dropin_headers_compile_with_host_compiler_and_need_a_gpu():
     if lib.wa_ctx_create(0, C.byref(h)) == 0:
         lib.wa_ctx_destroy(h)
         pytest.skip("a HIP device is present")
-    r = run_demo("dev", 1, "/tmp/weldacs_dropin_cpu.txt")
+    r = run_demo("dev", 1, TMPW + "weldacs_dropin_cpu.txt")
     assert r.returncode != 0 and "no CPU fallback" in r.stdout
 
 
@@ -78,7 +79,7 @@ def test_dropin_pipeline_ref_mode_equals_reference(stl):
         a, b = waf.load(os.path.join(G, "vox_cubic_ascii_p0219_w8.waf")), waf.load(os.path.join(G, "vox_cubic_p0219_w8.waf"))
         assert all(np.array_equal(a[k], b[k]) for k in ("dims", "cx", "cy", "cz", "free_packed"))
     compile_demo()
-    out = "/tmp/weldacs_dropin_ref.txt"
+    out = TMPW + "weldacs_dropin_ref.txt"
     r = run_demo("ref", 4321, out, stl)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = parse(out)
@@ -102,7 +103,7 @@ def test_dropin_pipeline_ref_mode_equals_reference(stl):
 @pytest.mark.gpu
 def test_dropin_pipeline_dev_mode_is_deterministic_and_sane():
     compile_demo()
-    a, b = "/tmp/weldacs_dropin_dev_a.txt", "/tmp/weldacs_dropin_dev_b.txt"
+    a, b = TMPW + "weldacs_dropin_dev_a.txt", TMPW + "weldacs_dropin_dev_b.txt"
     assert run_demo("dev", 7, a).returncode == 0 and run_demo("dev", 7, b).returncode == 0
     da, db = parse(a), parse(b)
     assert da["edges"] == db["edges"] and da["tour_L"] == db["tour_L"] and np.array_equal(da["gpath"], db["gpath"])
@@ -110,7 +111,7 @@ def test_dropin_pipeline_dev_mode_is_deterministic_and_sane():
     costs = np.array([da["cost"][(i, j)] for i in range(5) for j in range(5) if i != j])
     assert np.all(np.isfinite(costs)) and np.all(costs > 0)
     # lazy evaporation (the DEV default) and the dense sweep give the same bytes
-    c = "/tmp/weldacs_dropin_dev_c.txt"
+    c = TMPW + "weldacs_dropin_dev_c.txt"
     assert run_demo("dev-dense", 7, c).returncode == 0
     assert open(a, "rb").read() == open(c, "rb").read()
     # the correct (non-compat) graph file parses back to the in-memory matrix
@@ -125,14 +126,14 @@ def test_pair_loop_sharded_over_contexts_is_shard_invariant():
     -- gives the same costs and the same paths, bit for bit, with three slots per shard or with the slot count sized by
     rule (free memory, whole batches).  (One GPU here: an ordinal listed twice means two contexts on it.)"""
     libdir = os.path.dirname(_lib.LIB_PATH)
-    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    exe = TMPW + "weldacs_shard_check_%d" % os.getuid()
     r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
                         os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
     outs, shards = {}, {}
     for devs, slots in (("0", 3), ("0,0", 3), ("0,0,0", 3), ("all", 3), ("0", 0), ("0,0,0", 0), ("0,0,0,0,0,0,0,0", 0)):
-        out = "/tmp/weldacs_shard_%s_%d.txt" % (devs.replace(",", "_"), slots)
+        out = TMPW + "weldacs_shard_%s_%d.txt" % (devs.replace(",", "_"), slots)
         rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", devs, out, str(slots)],
                             capture_output=True, text=True)
         assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
@@ -162,14 +163,14 @@ def test_pair_loop_called_again_reuses_what_its_contexts_kept():
     device blocks of the solvers each call destroys (wa_ctx_cached_bytes), so the second and third call allocate nothing new -- what is kept
     stops growing -- and every call's costs and paths are those of a single call; trimDeviceMemory() hands everything back."""
     libdir = os.path.dirname(_lib.LIB_PATH)
-    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    exe = TMPW + "weldacs_shard_check_%d" % os.getuid()
     r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
                         os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
     outs = {}
     for calls in (1, 3):
-        out = "/tmp/weldacs_again_%d.txt" % calls
+        out = TMPW + "weldacs_again_%d.txt" % calls
         rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", "0,0,0", out, "0", str(calls)],
                             capture_output=True, text=True)
         assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
@@ -190,7 +191,7 @@ def test_pair_loop_deals_whole_end_point_groups_when_there_are_enough():
     longest-first (every end point lives on one shard), with one context nothing is dealt; costs and paths are the same bytes."""
     import oracle_lib as O
     libdir = os.path.dirname(_lib.LIB_PATH)
-    exe = "/tmp/weldacs_shard_check_%d" % os.getuid()
+    exe = TMPW + "weldacs_shard_check_%d" % os.getuid()
     r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "welding_robot_amd", "include"),
                         os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), "-L" + libdir, "-lweldacs", "-Wl,-rpath," + libdir, "-o", exe],
                        capture_output=True, text=True)
@@ -198,7 +199,7 @@ def test_pair_loop_deals_whole_end_point_groups_when_there_are_enough():
     tris = O.stl_parse(open(os.path.join(G, "cubic.stl"), "rb").read())
     og = O.grid_from_mesh(tris, np.float32("0.0219"), 8)
     nodes = [(4, 4, 4), (20, 27, 20), (4, 27, 20), (20, 4, 4), (12, 2, 12), (4, 4, 20), (20, 27, 4), (12, 29, 12), (2, 15, 12), (22, 15, 12)]
-    pts = "/tmp/weldacs_ten_points_%d.in" % os.getpid()
+    pts = TMPW + "weldacs_ten_points_%d.in" % os.getpid()
     with open(pts, "w") as f:
         f.write("%d\n" % len(nodes))
         for z, y, x in nodes:
@@ -206,7 +207,7 @@ def test_pair_loop_deals_whole_end_point_groups_when_there_are_enough():
             f.write("%f %f %f\n" % tuple(og.node_pt(z, y, x)))
     outs, shards = {}, {}
     for devs in ("0", "0,0"):
-        out = "/tmp/weldacs_groups_%s.txt" % devs.replace(",", "_")
+        out = TMPW + "weldacs_groups_%s.txt" % devs.replace(",", "_")
         rr = subprocess.run([exe, os.path.join(G, "cubic.stl"), "0.0219", "8", pts, "0.5", "99", devs, out, "0"], capture_output=True, text=True)
         assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
         outs[devs] = open(out, "rb").read()

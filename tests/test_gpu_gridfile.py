@@ -10,11 +10,12 @@ import pytest
 import oracle_lib as O
 import waf
 from welding_robot_amd import _lib, build
+from tmpw import TMPW
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-EXE = "/tmp/weldacs_gridfile_check_%d" % os.getuid()
+EXE = TMPW + "weldacs_gridfile_check_%d" % os.getuid()
 
 
 def bits(a):

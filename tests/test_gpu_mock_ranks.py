@@ -12,11 +12,12 @@ import sys
 
 import numpy as np
 import pytest
+from tmpw import TMPW
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-MOCK = "/tmp/weldacs_libmock_rccl_%d.so" % os.getuid()
-MOCK_DIR = "/tmp/weldacs_mock_rccl_%d" % os.getuid()
+MOCK = TMPW + "weldacs_libmock_rccl_%d.so" % os.getuid()
+MOCK_DIR = TMPW + "weldacs_mock_rccl_%d" % os.getuid()
 
 
 def build_mock():
@@ -63,7 +64,7 @@ def key(cost, rank, slot):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_every_exchange_of_the_communicator_between_ranks(world):
-    out = "/tmp/weldacs_mock_ranks_%d" % world
+    out = TMPW + "weldacs_mock_ranks_%d" % world
     run_ranks(world, [os.path.join(ROOT, "tests", "mock_rccl", "ranks.py"), out])
     R = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
     K = R[0]["cost"].size

@@ -9,9 +9,10 @@ import pytest
 
 import oracle_lib as O
 import waf
+from tmpw import TMPW
 
 pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/ref_harness not built (needs /root/reference)")
-TMP = "/tmp/weld_oracle_vs_ref_%d" % os.getuid()
+TMP = TMPW + "weld_oracle_vs_ref_%d" % os.getuid()
 os.makedirs(TMP, exist_ok=True)
 G = os.path.join(os.path.dirname(__file__), "golden")
 

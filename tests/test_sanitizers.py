@@ -12,10 +12,11 @@ import subprocess
 import sys
 
 import pytest
+from tmpw import TMPW
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
-OUT = "/tmp/weldacs_san_%d" % os.getuid()
+OUT = TMPW + "weldacs_san_%d" % os.getuid()
 G = os.path.join(ROOT, "tests", "golden")
 
 
@@ -63,13 +64,13 @@ def host_sources():
     return [
         ("mock_rccl", os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), ["-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"], [], None),
         ("shard_check", os.path.join(ROOT, "tests", "cpp", "shard_check.cpp"), inc, link,
-         [os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", "0,0", "/tmp/weldacs_san_shard.txt", "3"]),
+         [os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "99", "0,0", TMPW + "weldacs_san_shard.txt", "3"]),
         ("gridfile_check", os.path.join(ROOT, "tests", "cpp", "gridfile_check.cpp"), inc, link,
-         ["write", os.path.join(G, "cubic.stl"), "0.0219", "8", "/tmp/weldacs_san_grid.in", "0", "/tmp/weldacs_san_grid.txt"]),
+         ["write", os.path.join(G, "cubic.stl"), "0.0219", "8", TMPW + "weldacs_san_grid.in", "0", TMPW + "weldacs_san_grid.txt"]),
         ("dropin_demo", os.path.join(ROOT, "examples", "dropin_demo.cpp"), inc, link,
-         [os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", "/tmp/weldacs_san_graph.in", "dev", "3", "/tmp/weldacs_san_demo.txt"]),
-        ("multistart_rccl", os.path.join(ROOT, "examples", "multistart_rccl.cpp"), inc, link, ["16", "8", "4", "all", "/tmp/weldacs_san_ms.txt"]),
-        ("scalar_calls", os.path.join(ROOT, "examples", "scalar_calls.cpp"), inc, link, [os.path.join(G, "cubic.stl"), "0.0219", "8", "/tmp/weldacs_san_scalar.txt"]),
+         [os.path.join(G, "cubic.stl"), "0.0219", "8", os.path.join(G, "cubic_weld_points.in"), "0.5", TMPW + "weldacs_san_graph.in", "dev", "3", TMPW + "weldacs_san_demo.txt"]),
+        ("multistart_rccl", os.path.join(ROOT, "examples", "multistart_rccl.cpp"), inc, link, ["16", "8", "4", "all", TMPW + "weldacs_san_ms.txt"]),
+        ("scalar_calls", os.path.join(ROOT, "examples", "scalar_calls.cpp"), inc, link, [os.path.join(G, "cubic.stl"), "0.0219", "8", TMPW + "weldacs_san_scalar.txt"]),
     ]
 
 

@@ -9,10 +9,11 @@ import numpy as np
 import pytest
 
 from welding_robot_amd import _lib, api, build
+from tmpw import TMPW
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-EXE = "/tmp/weldacs_scalar_calls_%d" % os.getuid()
+EXE = TMPW + "weldacs_scalar_calls_%d" % os.getuid()
 
 
 def compile_exe():
