@@ -67,3 +67,18 @@ def test_bench_json_contract():
     sg = d["stragglers"]   # the hand-over engaged in the timed region and every straggler was finished
     assert sg["handed_over"] > 0 and sg["handed_over"] == sg["finished_by_resume_blocks"]
     assert abs(d["ms_per_step"] * d["value"] / 1e3 - 1.0) < 1e-6
+
+
+def test_a_failing_extra_does_not_cost_the_line():
+    """the extras stand outside `value`: when one of them throws (device memory, say), the driver must still get its JSON line, with the
+    failure reported under the extra's key"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu", "--no-roofline-256"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, WA_BENCH_FAIL="all"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 100 and d["steps"] == 10 and d["roofline"]["frac"] > 0.3
+    for k in ("walk_step", "full_run", "ref_mode", "multi_start", "multi_start_curve", "c5_pair_planning", "c5_full"):
+        assert "WA_BENCH_FAIL" in d[k]["error"], k
+    assert "walk_step_extra failed" in r.stderr
