@@ -458,6 +458,8 @@ def c5_sharded_extra(ctx, comm, rank, world, check_against_one_rank=True):
     # a rank whose share fails (out of device memory, say) must not leave the others waiting in the exchange: every rank reports, and
     # all of them give the leg up together
     try:
+        if os.environ.get("WA_BENCH_FAIL_RANK") == str(rank):     # (tests/test_gpu_mock_ranks.py: one rank fails, nobody hangs)
+            raise RuntimeError("WA_BENCH_FAIL_RANK")
         cost, paths, n_mine = pb.plan(ctx, grid, pts, gens, predict, seed, slots, rank, world, lazy=True)
         ctx.sync()
         failed = None

@@ -174,3 +174,15 @@ def test_bench_with_ranks_on_one_gpu(world):
     assert d["global_best_owner"][0] in (0, 1) and d["global_best_owner"][1] == 0
     assert d["best_cost_all_ranks"] <= d["best_cost"]
     assert "cpu_baseline" not in d and "multi_start" not in d          # N > 1: the timed job only
+
+
+def test_bench_survives_a_rank_that_cannot_plan_its_share():
+    """one rank of the sharded C5 leg fails before the exchange (out of device memory, say): the ranks agree to give the leg up -- nobody waits
+    in a collective for the rank that left --, rank 0 still prints the line with the headline, and the failure is reported under c5_sharded"""
+    outs = run_ranks(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"], timeout=300,
+                     extra_env={"WA_BENCH_C5": "48,9,40", "WA_BENCH_C5_SLOTS": "6", "WA_BENCH_FAIL_RANK": "1"})
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "another rank" in d["c5_sharded"]["error"]
+    assert "WA_BENCH_FAIL_RANK" in outs[1][2]       # rank 1 said why on its stderr
