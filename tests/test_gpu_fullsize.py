@@ -184,6 +184,14 @@ def test_c5_full_size_pair_planning_and_seam_order(ctx):
 
 
 # ------------------------------------------------------------------ C4 with the ranks a 1-GPU box has
+def _free_port():
+    """a port nobody listens on right now (a fixed one can still be in TIME_WAIT from the test before)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _bench(args, env=None, launcher=()):
     cmd = list(launcher) + [os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, env=dict(os.environ, **(env or {})), cwd=ROOT, timeout=900)
@@ -200,7 +208,7 @@ def test_c4_rccl_path_with_one_rank(path):
     (default), or torch.distributed.all_reduce(MIN) of the exported trace (WA_BENCH_TORCH_ALLREDUCE=1); bench.py asserts that
     the reduced history equals the rank's own.  What this does NOT show is a reduction over more than one rank's data: N > 1
     is covered by the 2-rank gloo test on the CPU and is unmeasured on hardware."""
-    port = 29500 + os.getpid() % 1000 + (7 if path == "torch" else 0)
+    port = _free_port()
     env = {"WA_FORCE_DIST": "1"}
     if path == "torch":
         env["WA_BENCH_TORCH_ALLREDUCE"] = "1"
@@ -214,7 +222,7 @@ def test_c4_rccl_path_with_one_rank(path):
 def test_c5_sharded_leg_with_one_rank_over_real_rccl():
     """bench.py's C5 strong-scaling leg (`c5_sharded`) with the one rank RCCL itself admits on a 1-GPU box: the grid broadcast, the cost all-gather
     and the path gather are ISSUED through librccl (no stand-in), and the result equals the plain one-rank plan.  (Several ranks: the mock-ranks test.)"""
-    port = 29500 + (os.getpid() + 17) % 2000
+    port = _free_port()
     d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "2", "--no-cpu", "--no-extras"], env={"WA_FORCE_DIST": "1", "WA_BENCH_C5": "96,16,80"},
                launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)])
     c5 = d["c5_sharded"]
