@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 B="--gpus 1 --warmup 5 --no-cpu --no-extras --no-roofline-256"
 # 1. the driver's line and the 500-generation line
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench20.json 2> $O/bench20.err
+sleep 8   # (the process before has just given 190 GB back: while the driver wipes them the host's launches are slower -- 63 instead of 43 us per generation seen once)
 python3 $R/bench.py --gpus 1 --steps 500 --warmup 5 --no-extras > $O/bench500.json 2>> $O/bench20.err
 # 2. kernel trace + stats of warm-up + timed region ONLY (--no-extras: nothing else is enqueued on the solver), cut at the timed region
 for K in 20 500; do
