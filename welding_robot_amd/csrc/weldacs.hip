@@ -89,6 +89,7 @@ struct wa_acs {
     int32_t *d_stage = nullptr;      // staging block of acs_fetch_results (the best paths of all slots, packed), grows on demand
     size_t stage_words = 0;
     // host copy of every slot's control block and best path behind the last run (acs_fetch_results): wa_acs_result / _batch read it
+    std::vector<float> ltab_host;    // host copy of D.ltab (uploaded asynchronously at creation)
     std::vector<WaSlotCtl> res_ctl;
     std::vector<int32_t> res_words;
     int64_t res_longest = 0;
