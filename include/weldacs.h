@@ -104,7 +104,9 @@ int wa_grid_info(const wa_grid *g, int32_t dims3[3], float *precision, int32_t *
 int wa_grid_read_occupancy(const wa_grid *g, uint8_t *free_out /* nx*ny*nz */);
 int wa_grid_read_coords(const wa_grid *g, float *cx, float *cy, float *cz);
 /* ACS_Rank::setPoints / checkRoutePoints (ACSRank_3D.hpp:537-565, :511-535): for each point the
- * LAST free voxel in raster order within +-(float)(1.2*precision) on every axis; -1 if none. */
+ * LAST free voxel in raster order within +-(float)(1.2*precision) on every axis; -1 if none.  Calls with up to 16 points (setPoints
+ * resolves two) are answered from a host mirror of the grid's axis tables and occupancy, fetched once per grid (0.2 us per call instead
+ * of a launch + synchronise + copy); larger batches by the kernel; WA_RESOLVE_HOST=0: always the kernel.  Same ids either way. */
 int wa_grid_resolve_points(const wa_grid *g, const float *pts_xyz, int32_t n_pts, int64_t *ids_out);
 
 /* ---- rank-based ACS: replaces ACS_Rank::initFromGridMap / computeSolution / reset /

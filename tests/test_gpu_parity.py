@@ -157,9 +157,23 @@ def test_resolve_points_last_match_wins(ctx):
     finally:
         del os.environ["WA_RESOLVE_DENSE"]
     assert got[0] == 4130 and got[1] == 17521 and got[3] == -1 and (want == -1).sum() >= 2
+    # calls with a few points (ACS_Rank::setPoints resolves two) are answered from a host mirror of the grid, larger ones by the kernel:
+    # the same ids either way, two points at a time, all at once, and with the mirror switched off
+    small = np.array([dg.resolve(pts[i:i + 2]) for i in range(0, len(pts), 2)]).reshape(-1)
+    assert np.array_equal(small, want)
+    os.environ["WA_RESOLVE_HOST"] = "0"
+    try:
+        assert np.array_equal(np.array([dg.resolve(pts[i:i + 2]) for i in range(0, len(pts), 2)]).reshape(-1), want)
+    finally:
+        del os.environ["WA_RESOLVE_HOST"]
     sg = O.synth_grid(128)
     dsg = dgrid_from(ctx, sg)
     assert dsg.resolve(np.array([[0, 0, 0], [127, 127, 127]], np.float32)).tolist() == [16513, 2097151]  # Q4
+    os.environ["WA_RESOLVE_HOST"] = "0"
+    try:
+        assert dsg.resolve(np.array([[0, 0, 0], [127, 127, 127]], np.float32)).tolist() == [16513, 2097151]
+    finally:
+        del os.environ["WA_RESOLVE_HOST"]
 
 
 # ------------------------------------------------------------------ ACS, REF mode == the reference itself

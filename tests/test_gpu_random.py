@@ -116,7 +116,9 @@ def test_random_meshes_voxelise_and_resolve(ctx, chunk):
         assert np.array_equal(dg.occupancy(), og.free), (chunk, i, nt, p, wall)
         pts = np.stack([rs.choice(og.cx, 12), rs.choice(og.cy, 12), rs.choice(og.cz, 12)], axis=1).astype(np.float32)
         pts += rs.uniform(-1.5 * p, 1.5 * p, pts.shape).astype(np.float32)
-        assert np.array_equal(dg.resolve(pts), np.array([og.resolve(q) for q in pts])), (chunk, i)
+        want = np.array([og.resolve(q) for q in pts])
+        assert np.array_equal(dg.resolve(pts), want), (chunk, i)                                   # 12 points: the host mirror of the grid
+        assert np.array_equal(dg.resolve(np.concatenate([pts, pts[::-1]])), np.concatenate([want, want[::-1]])), (chunk, i)   # 24: the kernel
         dg.close()
 
 

@@ -64,6 +64,11 @@ struct wa_grid {
     int64_t n_free;
     float *cx, *cy, *cz;   // device
     uint8_t *occ;          // device
+    // host mirror of the axis tables and the occupancy for calls that resolve a few points (wa_grid_resolve_points: ACS_Rank::setPoints
+    // resolves TWO): fetched on the first such call -- a grid does not change after it has been built
+    mutable std::vector<float> h_cx, h_cy, h_cz;
+    mutable std::vector<uint8_t> h_occ;
+    mutable bool h_valid = false;
 };
 struct wa_traj {
     wa_ctx *ctx;
