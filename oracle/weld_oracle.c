@@ -289,12 +289,14 @@ static void wo_is_get(wo_is *t)
 static void wo_is_float(wo_is *t, float *v)
 {
     if (!wo_is_sentry(t, 0)) return;
-    char x[512];
+    const size_t cap = t->n - t->pos + 4;            /* the filter passes at most what is left of the text (+ sign, '0', terminator) */
+    char *x = (char *)malloc(cap);
+    if (!x) { t->fail = 1; return; }
     size_t k = 0;
     int eof = t->pos >= t->n, mant = 0, dec = 0, sci = 0;
     int c = eof ? 0 : t->s[t->pos];
 #define WO_NEXT() do { if (++t->pos < t->n) c = t->s[t->pos]; else eof = 1; } while (0)
-#define WO_PUT(ch) do { if (k + 1 < sizeof x) x[k++] = (char)(ch); } while (0)
+#define WO_PUT(ch) do { if (k + 1 < cap) x[k++] = (char)(ch); } while (0)
     if (!eof && (c == '+' || c == '-')) { WO_PUT(c); WO_NEXT(); }
     while (!eof && c == '0') {              /* leading zeros collapse into one */
         if (!mant) { WO_PUT('0'); mant = 1; }
@@ -323,6 +325,7 @@ static void wo_is_float(wo_is *t, float *v)
     else if (r == INFINITY) { r = FLT_MAX; t->fail = 1; }
     else if (r == -INFINITY) { r = -FLT_MAX; t->fail = 1; }
     *v = r;
+    free(x);
     if (eof) t->eof = 1;
 }
 static int wo_tok_is(const uint8_t *p, size_t len, const char *w) { return len == strlen(w) && memcmp(p, w, len) == 0; }

@@ -131,7 +131,8 @@ def test_ascii_stl_reader_on_mutated_files():
     rs = np.random.RandomState(77)
     cubic = O.stl_parse(open(os.path.join(G, "cubic.stl"), "rb").read())
     std = stl_text.ascii_stl_text(cubic[:5])
-    junk = [b"facet", b"vertex", b"endsolid", b"1e", b".", b"-", b"+.e1", b"0x10", b"inf", b"1e400", b"-1e-400", b"12abc", b"\t", b"\n", b"\r\n", b"\v", b" "]
+    junk = [b"facet", b"vertex", b"endsolid", b"1e", b".", b"-", b"+.e1", b"0x10", b"inf", b"1e400", b"-1e-400", b"12abc", b"\t", b"\n", b"\r\n", b"\v", b" ",
+            b"0" * 600 + b"125", b"9" * 700 + b"e-690", b"1" + b"0" * 50, b"-." + b"0" * 520 + b"7e520"]   # numbers longer than any fixed buffer
     n_cmp = n_refused = 0
     for case in range(120):
         toks = std.replace(b"\n", b" \n ").split(b" ")

@@ -100,3 +100,54 @@ def test_host_side_cpp_compiles_and_runs_clean_under_asan_and_ubsan(name):
     # no device: the program says so and ends by itself (a crash would be a signal = a negative code; gridfile_check reports the
     # failure in its dump file and returns 0, the others return their error code)
     assert r.returncode >= 0 and "no CPU fallback" in out, (r.returncode, out[-1500:])
+
+
+def test_ascii_stl_reader_under_asan_and_ubsan():
+    """The library's ASCII STL reader (csrc/stl_text.hpp) is plain host C++: compiled on its own with the sanitizers and fed the committed text
+    files, damaged ones and files cut at every kind of place -- exactly sized heap buffers without a terminator, so a read one byte past the
+    text is reported -- and held against what libweldacs.so (the same code, built by hipcc) returns for the same bytes."""
+    import numpy as np
+    import stl_text
+    import waf
+    import oracle_lib as O
+    from welding_robot_amd import api
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "stl_text_check")
+    cmd = ["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror"] + SAN + ["-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "stl_text_check.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = waf.load(os.path.join(G, "stl_ascii.waf"))
+    datas = [bytes(g["file_" + t]) for t in bytes(g["tags"]).decode().split()]
+    rs = np.random.RandomState(11)
+    text = stl_text.ascii_stl_text(O.stl_parse(open(os.path.join(G, "cubic.stl"), "rb").read()))
+    junk = [b"facet", b"vertex", b"1e", b".", b"-", b"+.e1", b"inf", b"1e400", b"12abc", b"\n", b"\r\n", b"0" * 600, b"9" * 700 + b"e9999"]
+    for case in range(150):
+        toks = text.replace(b"\n", b" \n ").split(b" ")
+        for _ in range(int(rs.randint(1, 6))):
+            k = int(rs.randint(0, len(toks)))
+            toks[k:k + int(rs.randint(0, 3))] = [junk[int(rs.randint(0, len(junk)))]]
+        d = b" ".join(toks)
+        datas.append(d[:int(rs.randint(80, len(d) + 1))] if case % 2 else d)
+    datas.append(b"solid s\n" + b" " * 80 + b"facet")
+    files = []
+    for i, d in enumerate(datas):
+        f = os.path.join(OUT, "stl_%03d.stl" % i)
+        open(f, "wb").write(d)
+        files.append(f)
+    r = subprocess.run([exe] + files, capture_output=True, text=True, env=san_env())
+    assert r.returncode == 0 and clean_of_reports(r.stdout + r.stderr), (r.stdout[-1500:] + r.stderr[-3000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(datas)
+    refused = 0
+    for d, line in zip(datas, lines):
+        n, n2, n3, h = line.split()
+        try:
+            t = api.stl_parse(d)
+        except api.WeldacsError as e:
+            assert int(n) == -e.code == -5          # WA_ERR_FORMAT on both sides
+            refused += 1
+            continue
+        assert int(n) == int(n2) == len(t)
+        assert int(n3) == (-7 if len(t) else 0)     # WA_ERR_CAPACITY into a buffer one triangle short
+        assert int(h, 16) == O.fnv1a_bytes(np.ascontiguousarray(t, np.float32).tobytes())
+    assert refused >= 1

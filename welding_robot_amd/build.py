@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libweldacs.so")
 KNOBS_LIB_PATH = os.path.join(LIB_DIR, "libweldacs_knobs.so")
 SOURCES = ["weldacs.hip"]
 DEPS = ["wa_device.h", "acs_kernels.hpp", "acs_dev.hpp", "acs_walk.hpp", "acs_update.hpp", "acs_nb26.hpp", "walk_loop_gfx950.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp", "traj_kernels.hpp",
-        "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc", "host_comm.inc"]
+        "stl_text.hpp", "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc", "host_comm.inc"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "weldacs.h")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -26,6 +26,7 @@
 #include "grid_kernels.hpp"
 #include "gtsp_kernels.hpp"
 #include "traj_kernels.hpp"
+#include "stl_text.hpp"
 
 // ------------------------------------------------------------------ handles
 struct WaDevBlock { void *p; size_t bytes; unsigned long long stamp; };
