@@ -150,3 +150,44 @@ def test_kept_memory_is_bounded_and_goes_back_under_pressure():
           % (kept / GiB, dt, sa["released_bytes"] / GiB))
     b.close()
     a.close()
+
+
+def test_solvers_of_similar_shapes_reuse_each_others_blocks_as_they_stand():
+    """A host that plans job after job builds solvers of similar, not equal, shapes (the slot rule follows the number of pairs).  Address
+    ranges are never mapped twice (the stale-translation finding), so re-mapping every array for every new shape would walk through the
+    arena's 64 TiB of ranges -- tools/arena_stress.py: ~380 C5-sized solvers, then every later one from plain hipMalloc blocks in 4.9 s
+    instead of 0.09 s.  A kept block therefore also serves a request that is smaller by up to a third, as it stands: nothing is mapped,
+    nothing created, and the results are those of a solver built on a fresh context."""
+    ctx = make_ctx(WA_DEV_POISON=1)
+    if not ctx.cache_stats()["arena"]:
+        ctx.close()
+        pytest.skip("no virtual memory management on this device")
+    f, cx, cy, cz, prec, wall = synth.synth_grid(128, seed=2024, occ_prob=0.10)
+    g = api.Grid.from_occupancy(ctx, f, cx, cy, cz, prec, wall)
+    pts = synth.synth_weld_points(f, 128, 8, seed=3)
+    p = api.default_params(max_iteration=12, predict=float(24 / 0.35), rng_mode=api.RNG_DEV, seed=5)
+    og = O.Grid(cx, cy, cz, f, prec, wall)
+    a = O.Acs(og)
+    a.solve(int(pts[2]), int(pts[3]), 12, float(24 / 0.35), mode=O.DEV, seed=5, stream=1)
+    s = api.AcsSolver(ctx, g, n_slots=40, max_colony=24, lazy=True)
+    s.close()
+    kept = ctx.cached_bytes()
+    for slots in (36, 31, 40, 28, 39):          # 28 of 40: the smallest that still fits the blocks of 40 (a third smaller)
+        before = ctx.cache_stats()
+        s = api.AcsSolver(ctx, g, n_slots=slots, max_colony=24, lazy=True)
+        after = ctx.cache_stats()
+        assert after["miss_bytes"] - before["miss_bytes"] < (64 << 20), (slots, after["miss_bytes"] - before["miss_bytes"])   # (only the small blocks that never went through the arena)
+        s.solve(p, [int(pts[0]), int(pts[2])], [int(pts[1]), int(pts[3])], streams=[0, 1])
+        cost, path, _ = s.result(1)
+        assert bits(cost) == bits(a.best_L) and (not np.isfinite(cost) or np.array_equal(path, a.best_path()[0]))
+        assert np.array_equal(bits(s.pheromone(1)), bits(a.pheromone()))
+        s.close()
+        assert abs(ctx.cached_bytes() - kept) < (256 << 20)          # the same blocks go back as they came
+    # a much smaller solver is NOT served from those blocks as they stand (that would hold 40 slots' memory for 8): it is built from their chunks
+    before = ctx.cache_stats()
+    s = api.AcsSolver(ctx, g, n_slots=8, max_colony=24, lazy=True)
+    free_now, _ = ctx.memory_info()
+    s.close()
+    after = ctx.cache_stats()
+    assert after["miss_bytes"] - before["miss_bytes"] < (64 << 20)
+    ctx.close()

@@ -48,6 +48,7 @@ struct wa_ctx {
     bool cache_on = true, poison = false;      // WA_DEV_CACHE=0 / WA_DEV_POISON=1, read at wa_ctx_create
     // the arena (round 5): physical chunks of two sizes, created once and mapped into whatever virtual range the next block needs
     bool arena_on = false;                     // the device supports virtual memory management and WA_DEV_ARENA != 0
+    bool arena_strict = false;       // kept blocks are only reused for requests of exactly their size (the retry of a solver that did not fit)
     std::vector<hipMemGenericAllocationHandle_t> pool[3];   // kept chunks per size class (WA_ARENA_SZ), unmapped
     std::unordered_map<void *, WaArenaBlock> arena_live;    // blocks handed out
     std::vector<WaArenaBlock> arena_kept;                   // blocks given back, STILL MAPPED: a request of exactly that size takes one as it is
@@ -202,8 +203,8 @@ static int env_int(const char *name, int def)
 // MI355X), blocks of WA_ARENA_MIN bytes and up are built from CHUNKS: physical allocations of 512 MiB, 32 MiB and 2 MiB (a block = as
 // many big ones as fit, then its tail in the smaller classes: at most 15 + 15 of them, rounded up to 2 MiB like the driver's own granule)
 // mapped into a reserved address range.
-//   * A block that is given back stays MAPPED (arena_kept): a request of exactly its size takes it as it is -- the same solver shape
-//     created again maps nothing.
+//   * A block that is given back stays MAPPED (arena_kept): a request of its size, or smaller by up to a third, takes it as it stands --
+//     the same or a similar solver shape created again maps nothing (arena_alloc_locked says why the surplus is worth it).
 //   * A request no kept block fits takes chunks from the pools; when those run short, kept blocks are HARVESTED, least recently used
 //     first: unmapped, their chunks to the pools -- so a solver of ANY shape is built from what solvers of other shapes gave back, and
 //     only the difference is created fresh.
@@ -425,14 +426,24 @@ static void arena_return_chunks(wa_ctx *c, WaArenaBlock &b)
 static hipError_t arena_alloc_locked(wa_ctx *c, void **out, size_t bytes)
 {
     const size_t rounded = (bytes + WA_ARENA_SZ[2] - 1) / WA_ARENA_SZ[2] * WA_ARENA_SZ[2];
-    {   // a kept block of exactly this size: taken as it stands (most recently used first: its bytes are the likeliest to be in a cache)
+    {   // a kept block of this size, or the smallest one that is larger by up to half: taken as it stands, surplus included (of equals the
+        // most recently used first: its bytes are the likeliest to be in a cache).  The surplus is what keeps a process that builds solver
+        // after solver of SIMILAR shapes (224, 190, 207 ... slots) from re-mapping 190 GB into fresh address ranges every time: ranges
+        // are never used twice (above), so tools/arena_stress.py ran out of them after ~380 such solvers and every later one was built from
+        // plain hipMalloc blocks in 4.9 s instead of 0.09 s.  All arrays of a solver shrink and grow together, so what the larger blocks
+        // hold back is memory the context was keeping anyway; a request that cannot be met because of it is retried with exact sizes
+        // (arena_strict: acs_create).
         long best = -1;
-        for (size_t i = 0; i < c->arena_kept.size(); i++)
-            if (c->arena_kept[i].va_bytes == rounded && (best < 0 || c->arena_kept[i].stamp > c->arena_kept[(size_t)best].stamp)) best = (long)i;
+        for (size_t i = 0; i < c->arena_kept.size(); i++) {
+            const size_t vb = c->arena_kept[i].va_bytes;
+            if (vb < rounded || (vb != rounded && (c->arena_strict || vb - rounded > rounded / 2))) continue;
+            if (best < 0 || vb < c->arena_kept[(size_t)best].va_bytes ||
+                (vb == c->arena_kept[(size_t)best].va_bytes && c->arena_kept[i].stamp > c->arena_kept[(size_t)best].stamp)) best = (long)i;
+        }
         if (best >= 0) {
             WaArenaBlock b = std::move(c->arena_kept[(size_t)best]);
             c->arena_kept.erase(c->arena_kept.begin() + best);
-            c->cache_bytes -= rounded;
+            c->cache_bytes -= b.va_bytes;
             c->stat[WA_ST_HIT_BYTES] += (int64_t)rounded;
             c->stat[WA_ST_FULL_HITS]++;
             *out = b.va;
