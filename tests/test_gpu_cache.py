@@ -54,7 +54,8 @@ def test_solvers_on_reused_blocks_equal_the_oracle(case, poison):
         kept = ctx.cached_bytes()
         assert kept > 0
         free1, _ = ctx.memory_info()
-        assert abs(free1 - free0) < (256 << 20), "kept blocks count as free"
+        if not os.environ.get("PYTEST_XDIST_WORKER"):      # (the device's free memory is everybody's: other xdist workers allocate meanwhile)
+            assert abs(free1 - free0) < (256 << 20), "kept blocks count as free"
     ctx.trim()
     assert ctx.cached_bytes() == 0
     ctx.close()
