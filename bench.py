@@ -699,6 +699,16 @@ def main():
             fused = {"ms": fused["ms"] + more["ms"], "launches": fused["launches"] + more["launches"]}
             fused_where += " + %d of the same search continued behind it (stamping every launch inside the timed region would cost it 4 %%)" % more["launches"]
         fused_ms = fused["ms"] / max(fused["launches"], 1)
+        # ---- the same launch with the measurement's own share taken out: a dispatch WITH events directly behind one WITHOUT (the walk)
+        # starts its workgroups 1.2 us slower and reports 1.6-2 us more than the same dispatch behind another event-carrying one -- blocks,
+        # clock, L2 and TLB counters unchanged (profiles/r06/sweep_gap.txt).  `paired`: a stamped no-op dispatch in front of each timed launch
+        paired_ms = None
+        if not args.no_extras:
+            solver.profile(True, 1, paired=True)
+            solver.run(32)
+            pp = solver.profile_read()["evaporate"]
+            paired_ms = pp["ms"] / max(pp["launches"], 1)
+            solver.profile(False, 1)
         # ---- beside it: the sweep kernel on its own, at the BASELINE size and past the Infinity Cache
         r128 = sweep_roofline(ctx, n)
         r256 = sweep_roofline(ctx, 256) if not args.no_roofline_256 else None
@@ -741,6 +751,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": fused_ms, "sampled_launches": fused["launches"],
+                         "paired": None if not paired_ms else {
+                             "avg_launch_ms": paired_ms, "frac": alg_bytes / (paired_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "sampled_launches": 32,
+                             "note": "the same launch of the same search, 32 more generations, each timed launch preceded by a no-op dispatch that carries events "
+                                     "too: `frac` above includes 1.6-2 us that a dispatch with events reports when its predecessor (the walk) has none -- "
+                                     "slower workgroup start, same blocks, clock and cache counters (profiles/r06/sweep_gap.txt); `frac` stays the figure that "
+                                     "agrees with the rocprofv3 kernel stats, whose start stamp of such a dispatch coincides with its predecessor's end"},
                          "frac_hbm": (r256["achieved"] / HBM_PEAK_GBS) if r256 else None,
                          "note": "at 128^3 both 48 MiB buffers sit in the 256 MiB Infinity Cache: frac is an on-die figure; frac_hbm (= sweep_alone.frac_256: the same sweep "
                                  "on a 256^3 field, 805 MB per launch, non-temporal loads and stores by the library's rule) is the HBM one; multi_start.in_loop_frac is the "

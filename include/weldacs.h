@@ -65,7 +65,8 @@ int wa_ctx_cached_bytes(wa_ctx *ctx, int64_t *bytes);
 int wa_ctx_trim(wa_ctx *ctx);
 /* counters since the context was created: [0] blocks asked for (1 MiB and up), [1] bytes served from kept memory, [2] bytes newly
  * obtained from the driver, [3] bytes given back to the driver, [4] blocks served ENTIRELY from kept memory, [5] out-of-memory events
- * handled by releasing kept memory, [6] milliseconds spent building arena blocks, [7] 1 when the arena is in use */
+ * handled by releasing kept memory, [6] milliseconds spent building arena blocks, [7] 1 when the arena is in use, 2 when it is but its
+ * address window is used up (blocks kept so far go on serving, new shapes come as whole allocations) */
 int wa_ctx_cache_stats(wa_ctx *ctx, int64_t out[8]);
 /* Every call on a context (and on anything created from it) runs on that context's device regardless of the calling
  * thread's current HIP device, and restores the caller's current device before returning. */
@@ -240,7 +241,9 @@ int wa_acs_last_params(wa_acs *s, int32_t slot, int32_t *colony, float *lambda, 
 enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_COUNT = 4 };
 /* enable: 0 off; 1 every sample_every-th generation has all its launches stamped; 3 = the same, and the launch that carries the
  * evaporation sweep is stamped in EVERY generation (per-dispatch start/stop events of hipExtLaunchKernelGGL: no extra stream
- * operation, so the timed loop is not perturbed -- what bench.py's roofline figure uses) */
+ * operation, so the timed loop is not perturbed -- what bench.py's roofline figure uses); bit 2 (value 4) added to either: every
+ * stamped sweep-carrying launch is preceded by a no-op dispatch with events of its own -- a dispatch with events directly behind one
+ * without (the walk) reports 1.6-2 us that belong to that transition, not to the kernel (profiles/r06/sweep_gap.txt) */
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
 /* diagnostic counters.  Product build: out16[9] = ants handed over as stragglers, out16[7] = stragglers finished by a resume block (the two

@@ -111,10 +111,11 @@ def test_comm_id_is_shipped_over_a_socket_without_torch(tmp_path):
     assert wd.ship_unique_id(0, 1, lambda: b"x" * 128) == b"x" * 128
 
 
-def test_comm_id_server_turns_strangers_away_and_serves_every_rank_once(tmp_path):
-    """a port probe, a client of ANOTHER job and a rank that asks twice must not take a real rank's place: rank 0 serves ranks
-    1 and 2 exactly once each, whatever else connects in between; the stranger and the repeat are told no; a rank that never comes makes
-    rank 0 give up after its timeout instead of hanging."""
+def test_comm_id_server_turns_strangers_away_and_serves_every_rank_until_acknowledged(tmp_path):
+    """a port probe and a client of ANOTHER job must not take a real rank's place; a rank that never comes makes rank 0 give
+    up after its timeout instead of hanging.  ADVICE r05: a rank counts as served when its acknowledgement has arrived -- a client that
+    was cut off after the hello (here: one that hangs up without reading) does not count, the same rank asking again is served again,
+    and a rank number outside the world is turned away."""
     import threading
     import time
     port = _free_port()
@@ -132,16 +133,24 @@ def test_comm_id_server_turns_strangers_away_and_serves_every_rank_once(tmp_path
         with socket.create_connection(("127.0.0.1", port), timeout=5) as c:   # says nothing sensible and hangs up
             c.sendall(b"GET / HTTP/1.0\r\n\r\n")
 
-    th = [threading.Thread(target=run, args=(0, "jobA", "r0")), threading.Thread(target=probe),
+    def cut_off():   # rank 2 of the right job says hello and hangs up before it has read the id: it must NOT count as served
+        import struct
+        time.sleep(0.5)
+        with socket.create_connection(("127.0.0.1", port), timeout=5) as c:
+            c.sendall(wd._ID_MAGIC + struct.pack("<ii", 2, 3) + b"jobA".ljust(32, b"\0"))
+
+    th = [threading.Thread(target=run, args=(0, "jobA", "r0")), threading.Thread(target=probe), threading.Thread(target=cut_off),
           threading.Thread(target=run, args=(1, "jobB", "stranger", 0.4)),          # same port, another job
-          threading.Thread(target=run, args=(1, "jobA", "r1", 0.6)), threading.Thread(target=run, args=(1, "jobA", "r1 again", 1.2)),
+          threading.Thread(target=run, args=(7, "jobA", "rank 7 of 3", 0.5)),       # right job, impossible rank
+          threading.Thread(target=run, args=(1, "jobA", "r1", 0.6)), threading.Thread(target=run, args=(1, "jobA", "r1 again", 0.9)),
           threading.Thread(target=run, args=(2, "jobA", "r2", 1.6))]
     for t in th:
         t.start()
     for t in th:
         t.join(60)
     assert got.get("r0") == got.get("r1") == got.get("r2") == bytes(range(128)), (got.keys(), errs)
-    assert isinstance(errs.get("stranger"), RuntimeError) and "r1 again" in errs and set(got) == {"r0", "r1", "r2"}
+    assert isinstance(errs.get("stranger"), RuntimeError) and isinstance(errs.get("rank 7 of 3"), RuntimeError), errs
+    assert got.get("r1 again") == bytes(range(128)) and set(got) == {"r0", "r1", "r1 again", "r2"}, (got.keys(), errs)
     # a rank that never shows up: rank 0 fails after its timeout
     port = _free_port()
     t0 = time.time()

@@ -23,7 +23,7 @@ from welding_robot_amd import api, synth  # noqa: E402
 
 
 def setenv(knobs):
-    for k in ("WA_WALK_DIRECT", "WA_HASH_LOG2", "WA_WALK_WARM"):
+    for k in ("WA_WALK_DIRECT", "WA_HASH_LOG2", "WA_WALK_WARM", "WA_WALK_LDS_PAD"):
         os.environ.pop(k, None)
     for k, v in knobs.items():
         if v is not None:
@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--hash", default="0")
     ap.add_argument("--direct", default="0,1")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--pad", default="0", help="WA_WALK_LDS_PAD values (bytes of unused dynamic LDS per walk block: occupancy at a constant table)")
     ap.add_argument("--gens", type=int, default=100)
     ap.add_argument("--batches", action="store_true", help="--c5: seconds per batch (solve, reset, read-back)")
     ap.add_argument("--points", type=int, default=64)
@@ -47,6 +48,7 @@ def main():
     ctx = api.Context(0)
     hashes = [int(x) for x in a.hash.split(",")]
     directs = [int(x) for x in a.direct.split(",")]
+    pads = [int(x) for x in a.pad.split(",")]
     if a.c5:
         import plan_batch
         n = a.grid
@@ -56,8 +58,8 @@ def main():
         predict = float(0.35 ** -1 * 24)
         ref = None
         for h in hashes:
-            for d in directs:
-                setenv(dict(WA_WALK_DIRECT=d, WA_HASH_LOG2=h or None))
+            for d, pad in [(d, pad) for d in directs for pad in pads]:
+                setenv(dict(WA_WALK_DIRECT=d, WA_HASH_LOG2=h or None, WA_WALK_LDS_PAD=pad or None))
                 ts = []
                 for r in range(a.reps):
                     t0 = time.perf_counter()
@@ -67,7 +69,7 @@ def main():
                         print(json.dumps(dict(what="c5 batches", direct=d, hash_log2=h or "rule", rep=r, solve_reset_read_s=plan_batch.plan.last_batch_s)), flush=True)
                 if ref is None:
                     ref = cost
-                print(json.dumps(dict(what="c5", grid=n, points=a.points, direct=d, hash_log2=h or "rule", slots=plan_batch.plan.last_slots, t_pairs_s=[round(t, 4) for t in ts],
+                print(json.dumps(dict(what="c5", grid=n, points=a.points, direct=d, hash_log2=h or "rule", lds_pad=pad, slots=plan_batch.plan.last_slots, t_pairs_s=[round(t, 4) for t in ts],
                                       create_s=round(plan_batch.plan.last_create_s, 3), same_costs=bool(np.array_equal(cost, ref)))), flush=True)
         grid.close()
     if a.ms:
@@ -81,8 +83,8 @@ def main():
                 ref = None
                 for G in [int(x) for x in a.groups.split(",")]:
                     for h in hashes:
-                        for d in directs:
-                            setenv(dict(WA_WALK_DIRECT=d, WA_HASH_LOG2=h or None))
+                        for d, pad in [(d, pad) for d in directs for pad in pads]:
+                            setenv(dict(WA_WALK_DIRECT=d, WA_HASH_LOG2=h or None, WA_WALK_LDS_PAD=pad or None))
                             vals = []
                             for r in range(a.reps):
                                 out, hist, steps, _ = bench.multi_start_run(ctx, grid, ids, n, 256, P, G, a.gens, kind == "lazy", 5)
@@ -90,7 +92,7 @@ def main():
                                 if ref is None:
                                     ref = (hist, steps)
                             k = out["kernel_ms_per_launch"]
-                            print(json.dumps(dict(what="multi_start", kind=kind, P=P, G=G, direct=d, hash_log2=h or "rule", pgps=[round(v) for v in vals],
+                            print(json.dumps(dict(what="multi_start", kind=kind, P=P, G=G, direct=d, hash_log2=h or "rule", lds_pad=pad, pgps=[round(v) for v in vals],
                                                   walk_us=round(1e3 * k["walk"], 1), sweep_us=round(1e3 * k["evaporate"], 1),
                                                   same=bool(np.array_equal(hist, ref[0]) and np.array_equal(steps, ref[1])))), flush=True)
         grid.close()

@@ -321,8 +321,9 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))
         return c.value, np.float32(l.value), np.float32(q.value)
 
-    def profile(self, enable=True, sample_every=1, sweep_every_generation=False):
-        self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, (3 if sweep_every_generation else 1) if enable else 0, sample_every))
+    def profile(self, enable=True, sample_every=1, sweep_every_generation=False, paired=False):
+        """paired: every timed sweep-carrying launch is preceded by a stamped no-op dispatch (wa_acs_profile bit 2; why: profiles/r06/sweep_gap.txt)"""
+        self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, ((3 if sweep_every_generation else 1) | (4 if paired else 0)) if enable else 0, sample_every))
 
     def profile_read(self):
         ms = np.zeros(L.K_COUNT, np.float64)

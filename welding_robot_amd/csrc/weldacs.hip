@@ -71,6 +71,7 @@ struct wa_grid {
     mutable std::vector<float> h_cx, h_cy, h_cz;
     mutable std::vector<uint8_t> h_occ;
     mutable bool h_valid = false;
+    mutable std::mutex h_mu;   // guards the mirror's first fill (concurrent wa_grid_resolve_points calls on one grid)
 };
 struct wa_traj {
     wa_ctx *ctx;
@@ -109,6 +110,7 @@ struct wa_acs {
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     int walk_warm;         // touch loads in the hand-scheduled loop: -1 by launch size (wa_acs_run), 0 / 1 forced (WA_WALK_WARM)
+    int lds_pad;           // WA_WALK_LDS_PAD: experiment knob, extra dynamic LDS per walk block (occupancy at a constant table)
     int walk_direct;       // the loop WITHOUT look-ahead for saturated launches: -1 by rule (walk_direct_rule), 0 / 1 forced (WA_WALK_DIRECT)
     int walk_flags;        // k_walk_dev's switches: hand-scheduled loop, re-entry onto the replay track (WA_REENTRY=0: off), see acs_create
     WaRun R;
@@ -128,6 +130,7 @@ struct wa_acs {
     long long heur_batch;
     // profiling
     bool prof, prof_sweep_all;   // prof_sweep_all: the sweep-carrying launch of EVERY generation carries its own start/stop events
+    bool prof_paired;            // a stamped no-op dispatch in front of every timed sweep-carrying launch (prof_pair_marker)
     int32_t prof_every;
     std::vector<EvPair> ev;
     double prof_ms[WA_K_COUNT];
@@ -249,23 +252,32 @@ static hipMemAllocationProp arena_prop(int device)
 // tries again; when the region is used up (64 TiB of blocks re-mapped: hundreds of C5-sized reshapes) the arena stops building blocks
 // and the caller falls back to whole hipMalloc blocks.
 static const uintptr_t WA_VA_FIRST = (uintptr_t)32 << 40, WA_VA_END = (uintptr_t)96 << 40;
-static uintptr_t g_va_cursor = WA_VA_FIRST;
+static uintptr_t g_va_cursor = WA_VA_FIRST, g_va_end = WA_VA_END;
+static bool g_va_exhausted = false;   // the window is used up, or the platform does not honour address hints: no new arena blocks in this process
+static bool g_va_nohint = false;      // WA_DEV_ARENA_NOHINT=1 (test knob): reserve without a hint, i.e. what a platform that ignores hints would do
+// The cursor advances by what a block takes (rounded to the 2 MiB granule by the caller) plus a 2 MiB gap, aligned like the largest chunk
+// class the block holds -- 1 GiB for blocks of 512 MiB and up, 32 MiB, 2 MiB -- so that the translation of a chunk is not split by its
+// address (round 5 advanced by whole GiB: a small solver's forty 2-50 MiB blocks used up the window as fast as a C5-sized solver's).
 static hipError_t va_reserve_fresh_locked(size_t bytes, void **out)
 {
     *out = nullptr;
+    if (g_va_exhausted) return hipErrorOutOfMemory;
+    const uintptr_t align = bytes >= WA_ARENA_SZ[0] ? (uintptr_t)1 << 30 : bytes >= WA_ARENA_SZ[1] ? (uintptr_t)WA_ARENA_SZ[1] : (uintptr_t)WA_ARENA_SZ[2];
     for (int tries = 0; tries < 8; tries++) {
-        if (g_va_cursor + bytes > WA_VA_END) return hipErrorOutOfMemory;
-        void *hint = (void *)g_va_cursor, *va = nullptr;
-        const hipError_t e = hipMemAddressReserve(&va, bytes, 0, hint, 0);
-        if (e != hipSuccess) { (void)hipGetLastError(); g_va_cursor += (uintptr_t)1 << 40; continue; }
+        const uintptr_t start = (g_va_cursor + align - 1) & ~(align - 1);
+        if (start + bytes > g_va_end || start + bytes < start) { g_va_exhausted = true; return hipErrorOutOfMemory; }
+        void *hint = (void *)start, *va = nullptr;
+        const hipError_t e = hipMemAddressReserve(&va, bytes, 0, g_va_nohint ? nullptr : hint, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); g_va_cursor = start + ((uintptr_t)1 << 40); continue; }
         if (va == hint) {
-            g_va_cursor += (bytes + (((uintptr_t)1 << 30) - 1)) & ~(((uintptr_t)1 << 30) - 1);   // (1 GiB steps: ranges never touch)
+            g_va_cursor = start + bytes + (uintptr_t)WA_ARENA_SZ[2];   // (a 2 MiB gap: ranges never touch)
             *out = va;
             return hipSuccess;
         }
         hipMemAddressFree(va, bytes);              // somewhere else: not known to be fresh
-        g_va_cursor += (uintptr_t)1 << 40;
+        g_va_cursor = start + ((uintptr_t)1 << 40);
     }
+    g_va_exhausted = true;   // eight hints in a row refused or answered elsewhere: this platform does not place ranges where they are asked for
     return hipErrorOutOfMemory;
 }
 // a kept (mapped, idle) block gives its chunks to the pools; its address range is given back and never handed out again
@@ -451,13 +463,16 @@ static hipError_t arena_alloc_locked(wa_ctx *c, void **out, size_t bytes)
             return hipSuccess;
         }
     }
+    // (the address range first: when the window is used up no chunk is taken from the pools or created only to be put back -- ADVICE r05)
+    void *va = nullptr;
+    hipError_t e = c->arena_on ? va_reserve_fresh_locked(rounded, &va) : hipErrorOutOfMemory;   // a range nobody has been mapped at
+    if (e != hipSuccess) { *out = nullptr; return e; }
     size_t cnt[3], rest = rounded;
     for (int k = 0; k < 3; k++) { cnt[k] = rest / WA_ARENA_SZ[k]; rest %= WA_ARENA_SZ[k]; }
     WaArenaBlock b;
     b.va = nullptr;
     b.va_bytes = rounded;
     b.stamp = 0;
-    hipError_t e = hipSuccess;
     size_t from_kept = 0;
     for (int k = 0; k < 3; k++)
         for (size_t i = 0; i < cnt[k] && e == hipSuccess; i++) {
@@ -469,9 +484,7 @@ static hipError_t arena_alloc_locked(wa_ctx *c, void **out, size_t bytes)
                 if (kept) from_kept += WA_ARENA_SZ[k];
             }
         }
-    void *va = nullptr;
     size_t mapped = 0;
-    if (e == hipSuccess) e = va_reserve_fresh_locked(rounded, &va);   // a range nobody has been mapped at
     if (e == hipSuccess) {
         for (int k = 0; k < 3; k++)
             for (size_t i = 0; i < b.chunks[k].size() && e == hipSuccess; i++) {
@@ -509,7 +522,8 @@ static void cache_enforce_limits_locked(wa_ctx *c)
 {
     size_t whole = 0;
     for (auto &b : c->cache) whole += b.bytes;
-    const size_t small_limit = c->arena_on ? c->small_cache_limit : c->keep_limit;
+    // (once the arena has stopped building blocks -- address window used up -- whole blocks are what is kept, up to the context's limit)
+    const size_t small_limit = (c->arena_on && !g_va_exhausted) ? c->small_cache_limit : c->keep_limit;
     if (whole > small_limit) {
         std::sort(c->cache.begin(), c->cache.end(), [](const WaDevBlock &a, const WaDevBlock &b) { return a.stamp > b.stamp; });
         while (!c->cache.empty() && whole > small_limit) {
@@ -530,7 +544,7 @@ static hipError_t ctx_alloc_bytes(wa_ctx *c, void **out, size_t bytes)
     if (big) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         c->stat[WA_ST_ALLOCS]++;
-        if (c->arena_on && bytes >= WA_ARENA_MIN) {
+        if ((c->arena_on || !c->arena_kept.empty()) && bytes >= WA_ARENA_MIN) {   // (kept blocks go on serving when no new ones are built)
             const auto t0 = std::chrono::steady_clock::now();
             const hipError_t e = arena_alloc_locked(c, out, bytes);
             c->stat[WA_ST_WAIT_MS] += (int64_t)(1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -646,6 +660,12 @@ int wa_ctx_create(int device_ordinal, wa_ctx **out)
     }
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
+        // test knobs of the arena's fall-backs (tests/test_gpu_arena.py), process-wide like the window itself: WA_DEV_ARENA_VA_MB = size of
+        // the address window in MiB (0: nothing -- every block a whole allocation although the arena is on), WA_DEV_ARENA_NOHINT=1 = reserve
+        // without address hints, i.e. a platform that does not place ranges where they are asked for
+        const int va_mb = env_int("WA_DEV_ARENA_VA_MB", -1);
+        if (va_mb >= 0 && g_va_end == WA_VA_END) g_va_end = WA_VA_FIRST + ((uintptr_t)va_mb << 20);
+        if (env_int("WA_DEV_ARENA_NOHINT", 0)) g_va_nohint = true;
         g_cache_ctxs.push_back(c);
     }
     *out = c;
@@ -684,7 +704,7 @@ int wa_ctx_cache_stats(wa_ctx *c, int64_t out[8])
     if (!c || !out) return WA_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (int i = 0; i < 7; i++) out[i] = c->stat[i];
-    out[7] = c->arena_on ? 1 : 0;
+    out[7] = c->arena_on ? (g_va_exhausted ? 2 : 1) : 0;   // 2: in use, but its address window is used up -- new shapes come as whole blocks
     return WA_OK;
 }
 int wa_ctx_trim(wa_ctx *c)

@@ -50,9 +50,11 @@ _ID_MAGIC = b"WAID1"
 
 def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0, job=None):
     """The 128-byte id of a wa_comm from rank 0 to the other ranks of one job without torch / MPI: rank 0 listens on
-    MASTER_ADDR : MASTER_PORT + 1000 and serves every rank 1 .. world-1 EXACTLY ONCE.  A client introduces itself with a magic
-    word, its rank, the world size and a job tag (`job`, default: TORCHELASTIC_RUN_ID or MASTER_PORT); anything else that connects
-    -- a port probe, a leftover rank of another job, a rank asking twice -- is turned away and does not take a real rank's place.
+    MASTER_ADDR : MASTER_PORT + 1000 and serves every rank 1 .. world-1 until each has ACKNOWLEDGED the id.  A client introduces itself
+    with a magic word, its rank, the world size and a job tag (`job`, default: TORCHELASTIC_RUN_ID or MASTER_PORT); anything else that
+    connects -- a port probe, a leftover rank of another job -- is turned away and does not take a real rank's place.  A rank counts as
+    served when its one-byte acknowledgement has arrived, not when the id was sent: a client that was cut off before it had read the id
+    asks again and is served again (same rank, same tag) instead of being turned away while rank 0 goes on as if all was well.
     Every socket has a timeout: a rank that never shows up makes rank 0 fail after timeout_s instead of hanging, and a client that
     was turned away or cut off raises.  make_id() is only called on rank 0."""
     import socket
@@ -98,10 +100,11 @@ def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0, 
                     ok = hello is not None and hello[:len(_ID_MAGIC)] == _ID_MAGIC and hello[len(_ID_MAGIC) + 8:] == tag
                     if ok:
                         r, w = struct.unpack("<ii", hello[len(_ID_MAGIC):len(_ID_MAGIC) + 8])
-                        ok = w == world and r in waiting
+                        ok = w == world and 1 <= r < world       # (a rank that was served before may ask again: its ack may have been lost)
                     if ok:
                         c.sendall(b"OK" + uid)
-                        waiting.discard(r)
+                        if recv_exact(c, 1) == b"A":               # the client has the whole id
+                            waiting.discard(r)
                     else:
                         c.sendall(b"NO")
                 except OSError:
@@ -127,9 +130,10 @@ def ship_unique_id(rank, world, make_id, port=None, addr=None, timeout_s=120.0, 
             if head == b"OK":
                 buf = recv_exact(c, 128)
                 if buf is not None:
+                    c.sendall(b"A")           # only now does rank 0 stop waiting for this rank
                     return buf
             elif head == b"NO":
-                raise RuntimeError("ship_unique_id: rank 0 turned rank %d away (another job on this port, or this rank asked twice)" % rank)
+                raise RuntimeError("ship_unique_id: rank 0 turned rank %d away (another job on this port, or a rank number outside its world)" % rank)
         except OSError:
             pass                              # cut off mid-way (rank 0 not serving yet / a stale listener): try again until the deadline
         finally:
