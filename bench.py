@@ -440,12 +440,16 @@ def c5_sharded_extra(ctx, comm, rank, world, check_against_one_rank=True):
     seed, predict = 7, float(24 / 0.35)
     free = None
     t0 = time.perf_counter()
-    if rank == 0:
-        free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
-        mine_grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
-    else:
-        mine_grid = None
-    comm.barrier()
+    mine_grid, grid_err = None, None
+    if rank == 0:   # (a root that cannot build its grid must say so BEFORE the others enter the broadcast: ADVICE r05)
+        try:
+            free, cx, cy, cz, prec, wall = synth.synth_grid(n, seed=2024, occ_prob=0.10)
+            mine_grid = api.Grid.from_occupancy(ctx, free, cx, cy, cz, prec, wall)
+        except Exception as e:   # noqa: BLE001
+            grid_err = "rank 0 could not build the grid: %r" % (e,)
+            print("[bench] c5_sharded: " + grid_err, file=sys.stderr, flush=True)
+    if comm.allreduce([0.0 if grid_err is None else 1.0], "max")[0] != 0.0:   # (doubles as the barrier in front of the timed broadcast)
+        return {"error": grid_err or "rank 0 could not build the grid"} if rank == 0 else None
     t1 = time.perf_counter()
     grid = comm.broadcast_grid(mine_grid, root=0)
     t_bcast = time.perf_counter() - t1
@@ -489,7 +493,7 @@ def c5_sharded_extra(ctx, comm, rank, world, check_against_one_rank=True):
         pairs = len(pair_list)
         out = {"workload": "%d^3 grid, %d weld points = %d pair searches x %d generations dealt over %d rank(s), lazy evaporation; then the seam order on rank 0"
                            % (n, P, pairs, gens, world),
-               "scaling": "strong", "ranks": world, "pairs": pairs, "pairs_per_rank_mean": t_sum[1] / world, "slots_rank0": pb.plan.last_slots,
+               "scaling": "strong", "ranks": world, "rccl": comm.stats(), "pairs": pairs, "pairs_per_rank_mean": t_sum[1] / world, "slots_rank0": pb.plan.last_slots,
                "pair_generations_per_s": pairs * gens / t_all[1], "t_job_s_slowest_rank": t_all[1],
                "t_search_s": {"slowest": t_all[0], "fastest": t_min[0], "mean": t_sum[0] / world, "imbalance_max_over_mean": t_all[0] / (t_sum[0] / world)},
                "t_exchange_s_slowest_rank": t_all[2], "t_grid_broadcast_s": t_bcast, "grid_broadcast_bytes": int(n) ** 3 + 12 * n,
@@ -803,8 +807,16 @@ def main():
             print("[bench] rank %d: c5_sharded failed: %r" % (rank, e), file=sys.stderr, flush=True)
             c5s = {"error": repr(e)[:500]}
     if rank == 0:
+        if comm is not None:
+            # what RCCL ITSELF says about the communicator the line was produced on (not WORLD_SIZE): ranks = ncclCommCount, version = ncclGetVersion
+            # (0: the one-GPU stand-in of tests/mock_rccl answered), collectives issued by rank 0 (VERDICT r05 task 6c)
+            try:
+                out["rccl"] = comm.stats()
+            except Exception as e:   # noqa: BLE001
+                out["rccl"] = {"error": repr(e)[:200]}
         if c5s is not None:
             out["c5_sharded"] = c5s
+            out["c5_sharded_ranks"] = c5s.get("ranks") if isinstance(c5s, dict) else None
         if world == 1 and not args.no_cpu:
             # the CPU leg comes last (the extras before it are host-paced: 0.52-0.84 s for the C5 extra from box to box, whatever runs in front)
             out.update(cpu_baseline(args, free, n, trace, wl, path, K, elapsed * 1e3))

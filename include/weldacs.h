@@ -289,6 +289,16 @@ int wa_comm_unique_id(uint8_t id_out[WA_COMM_ID_BYTES]);
 int wa_comm_create(wa_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[WA_COMM_ID_BYTES], wa_comm **out);
 void wa_comm_destroy(wa_comm *c);
 int wa_comm_info(const wa_comm *c, int32_t *rank, int32_t *world);
+/* Every wait of the exchanges below is bounded and watches the communicator (ncclCommGetAsyncError): a peer that died, or that does not
+ * answer within WA_COMM_TIMEOUT_S seconds (environment, read by wa_comm_create; default 600, 0 = wait for ever), makes the call give the
+ * communicator up (ncclCommAbort) and return WA_ERR_DEVICE instead of blocking; every later call on it returns WA_ERR_STATE.
+ * wa_comm_abort does the same on request (a host that has learnt by other means that a peer is gone); wa_comm_destroy is still due.
+ * The reference has no counterpart (its pair loop is one process: ACSRank_3D.hpp:472-499); the convention is SURVEY 8(b)'s: status
+ * codes, never a hang.
+ * wa_comm_stats: [0] ranks as RCCL counts them (ncclCommCount), [1] RCCL's version code (ncclGetVersion), [2] all-reduce calls issued on
+ * this communicator, [3] other collectives / sends / receives issued, [4] 1 once the communicator has been aborted. */
+int wa_comm_abort(wa_comm *c);
+int wa_comm_stats(wa_comm *c, int64_t out[5]);
 /* global_best[g] = MIN over all ranks and all active slots of best_L[g] for g in [gen0, gen0 + count), together with WHO holds it:
  * one ncclAllReduce(ncclUint64, ncclMin) of the packed key (float bits of the cost << 32 | rank << 16 | slot; costs are non-negative
  * or +inf, so the bits order like the values; ties go to the lowest rank, then the lowest slot).  Asynchronous -- waits (event) for

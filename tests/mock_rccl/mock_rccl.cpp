@@ -1,4 +1,4 @@
-// mock_rccl.cpp -- TEST INFRASTRUCTURE, not part of the product: a stand-in for the twelve RCCL entry points libweldacs.so calls
+// mock_rccl.cpp -- TEST INFRASTRUCTURE, not part of the product: a stand-in for the fifteen RCCL entry points libweldacs.so calls
 // (csrc/host_comm.inc), so that the multi-rank paths of wa_comm_* can be run with world > 1 on a box that has ONE GPU -- RCCL itself
 // refuses two ranks on one device.  LD_PRELOADed in front of librccl by tests/test_gpu_mock_ranks.py; ranks are processes or threads
 // that share the GPU and exchange through files in a directory named by the unique id (MOCK_RCCL_DIR, default /tmp/mock_rccl_<uid>).
@@ -235,6 +235,23 @@ ncclResult_t ncclRecv(void *recv, size_t count, ncclDataType_t t, int peer, nccl
     snprintf(name, sizeof name, "/p%d_%d.%ld", peer, c->rank, c->received[(size_t)peer]++);
     if (hipStreamSynchronize(st) != hipSuccess || !get_file(c->dir + name, got.data(), got.size())) return ncclSystemError;
     return to_dev(recv, got.data(), got.size()) ? ncclSuccess : ncclSystemError;
+}
+
+ncclResult_t ncclCommAbort(ncclComm_t comm)
+{
+    delete comm;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->nranks;
+    return ncclSuccess;
+}
+ncclResult_t ncclGetVersion(int *version)
+{
+    if (version) *version = 0;   // "not RCCL"
+    return ncclSuccess;
 }
 
 ncclResult_t ncclGroupStart() { return ncclSuccess; }

@@ -18,8 +18,74 @@ from welding_robot_amd import dist as wd  # noqa: E402
 from test_gpu_edges import box_grid  # noqa: E402
 
 
+def fail_inside(out):
+    """RANKS_MODE=fail_inside (the -DWA_TEST_KNOBS build: WELDACS_LIB): a rank runs out of staging memory INSIDE an exchange -- behind the first
+    header round -- and every rank leaves that call with an error, together; the communicator goes on working; then the last rank leaves
+    without a word and the others' next exchange ends with an error within the stand-in's timeout instead of hanging; an aborted
+    communicator refuses every further call (VERDICT r05 task 6)."""
+    import ctypes as C
+    import time
+    from welding_robot_amd._lib import WeldacsError
+    rank, _, world = wd.env_rank()
+    ctx = api.Context(0)
+    ver = ctx.lib.wa_version().decode()
+    assert "knobs" in ver.lower() or "KNOBS" in ver, ver
+    uid = wd.ship_unique_id(rank, world, api.Comm.unique_id)
+    comm = api.Comm(ctx, rank, world, np.frombuffer(uid, np.uint8))
+    st = comm.stats()
+    assert st["ranks"] == world and st["version"] == 0 and not st["aborted"], st        # (version 0: the stand-in answers, not RCCL)
+    errs = []
+    ctx.lib.wa_test_comm_fail_scratch.argtypes = [C.c_void_p, C.c_int32]
+    # (a) rank 1's staging allocation fails inside wa_comm_gather_paths (root = last rank: rank 1 is a sender, or the root when world == 2)
+    if rank == 1:
+        assert ctx.lib.wa_test_comm_fail_scratch(comm.h, 1) == 0
+    try:
+        comm.gather_paths({10 * rank + i: np.arange(3 + i, dtype=np.int32) for i in range(2)}, root=world - 1)
+        errs.append(0)
+    except WeldacsError as e:
+        errs.append(e.code)
+    # (b) rank 0's record buffer fails inside wa_comm_allgather_costs
+    if rank == 0:
+        assert ctx.lib.wa_test_comm_fail_scratch(comm.h, 1) == 0
+    try:
+        comm.allgather_costs([rank], [1.0 + rank], world, fill=0.0)
+        errs.append(0)
+    except WeldacsError as e:
+        errs.append(e.code)
+    # (c) the communicator still works, and the same calls succeed now
+    after = comm.allreduce([float(rank)], "sum")
+    vec = comm.allgather_costs([rank], [1.0 + rank], world, fill=0.0)
+    got = comm.gather_paths({10 * rank: np.arange(4, dtype=np.int32)}, root=0)
+    # (d) the last rank leaves; the others' next exchange must END (error), not hang
+    t_dead = -1.0
+    dead_code = 0
+    if rank != world - 1:
+        t0 = time.time()
+        try:
+            comm.barrier()
+        except WeldacsError as e:
+            dead_code = e.code
+        t_dead = time.time() - t0
+        # (e) ... and an aborted communicator refuses every further call at once
+        comm.abort()
+        try:
+            comm.allreduce([1.0], "sum")
+            ab = 0
+        except WeldacsError as e:
+            ab = e.code
+        assert comm.stats()["aborted"]
+    else:
+        ab = -1
+    np.savez(out + ".rank%d.npz" % rank, errs=np.array(errs), after=after, vec=vec, n_got=np.array([len(got)]), t_dead=np.array([t_dead]),
+             dead_code=np.array([dead_code]), ab=np.array([ab]), other_calls=np.array([comm.stats()["other_calls"]]))
+    comm.close()
+    ctx.close()
+
+
 def main():
     out = sys.argv[1]
+    if os.environ.get("RANKS_MODE") == "fail_inside":
+        return fail_inside(out)
     rank, _, world = wd.env_rank()
     ctx = api.Context(0)                       # every rank on the one GPU
     uid = wd.ship_unique_id(rank, world, api.Comm.unique_id)

@@ -191,3 +191,40 @@ def test_solvers_of_similar_shapes_reuse_each_others_blocks_as_they_stand():
     after = ctx.cache_stats()
     assert after["miss_bytes"] - before["miss_bytes"] < (64 << 20)
     ctx.close()
+
+
+def _fallback_child(mode, slots, timeout=420):
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "arena_fallback_child.py"), mode, str(slots)],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print("arena fall-back %s: %s" % (mode, out))
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_arena_fallbacks_without_the_arena_on_the_c5_sized_sequence():
+    """WA_DEV_ARENA=0 -- what a device without virtual memory management runs -- on the sequence that broke round 4
+    (8-, 32-slot 128^3 solvers, then the C5-sized one, twice), in the driver-run suite: right results on poisoned memory, the second C5-sized
+    creation served from the kept whole blocks, bounded time."""
+    o = _fallback_child("noarena", 0)
+    assert o["arena_at_start"] == 0 and o["arena_at_end"] == 0 and o["equals_oracle"] and o["slots"] >= 200
+    assert o["t_big_s"][0] < 60 and o["t_big_s"][1] < 2.0, o["t_big_s"]        # first: the driver's wipe of what the small solvers gave back; second: exact-fit reuse
+    assert o["hit_gib"] > 150
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["nohint", "smallwindow"])
+def test_arena_fallbacks_when_address_ranges_are_refused_or_run_out(mode):
+    """... and the two ways the arena can stop building blocks: a platform that does not honour address hints (every hint answered elsewhere:
+    given up after eight, for good) and an address window that is used up in the middle of a solver (the cursor now advances by
+    block size, the exhaustion is final, reported -- wa_ctx_cache_stats [7] == 2 -- and later blocks are whole allocations kept up to the
+    context's limit).  Right results, bounded time, the repeated creation served from kept memory."""
+    o = _fallback_child(mode, 64)
+    if o["arena_at_start"] == 0:
+        pytest.skip("no virtual memory management on this device")
+    assert o["arena_at_end"] == 2 and o["equals_oracle"], o
+    assert o["t_big_s"][0] < 60 and o["t_big_s"][1] < 2.0, o["t_big_s"]

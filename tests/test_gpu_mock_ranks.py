@@ -1,5 +1,5 @@
 """The multi-rank paths of the library's communicator (wa_comm_*, csrc/host_comm.inc: SURVEY 8(e)'s three exchanges) with world = 2 and 3
-on a box that has ONE GPU.  RCCL refuses two ranks on one device, so the twelve RCCL entry points the library calls are replaced by
+on a box that has ONE GPU.  RCCL refuses two ranks on one device, so the fifteen RCCL entry points the library calls are replaced by
 tests/mock_rccl (LD_PRELOAD; file exchange between processes that share the GPU): what runs is every line of the library around the
 collectives -- packed keys and owners, size prefixes, padding, offsets at a root that is not rank 0, ragged and empty contributions --
 which a world of one rank (tests/test_comm.py, the most a 1-GPU box offers RCCL itself) never exercises.  Not a test of RCCL."""
@@ -41,7 +41,8 @@ def run_ranks(world, argv, timeout=240, extra_env=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60", WA_BENCH_BACKEND="gloo", **(extra_env or {}))
+                   LD_PRELOAD=MOCK, MOCK_RCCL_DIR=MOCK_DIR, MOCK_RCCL_TIMEOUT_S="60", WA_BENCH_BACKEND="gloo")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -121,6 +122,29 @@ def test_every_exchange_of_the_communicator_between_ranks(world):
     for r in range(world):
         assert R[r]["errs"].tolist() == [1, 1, 1], (r, R[r]["errs"])
         assert R[r]["after"].tolist() == [float(sum(range(world)))]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_that_fails_inside_an_exchange_and_a_rank_that_leaves(world):
+    """VERDICT r05 task 6: one rank's staging allocation fails INSIDE wa_comm_gather_paths / wa_comm_allgather_costs (behind the first header
+    round; forced through the knobs build): every rank gets WA_ERR_ALLOC from that very call, nobody waits for a partner that has left it,
+    and the communicator goes on working; a rank that exits without a word makes its peers' next exchange end with an error in bounded
+    time; an aborted communicator refuses further calls with WA_ERR_STATE."""
+    from welding_robot_amd import build as wb
+    knobs = wb.build_knobs()
+    out = TMPW + "weldacs_mock_fail_%d" % world
+    run_ranks(world, [os.path.join(ROOT, "tests", "mock_rccl", "ranks.py"), out], extra_env=dict(RANKS_MODE="fail_inside", WELDACS_LIB=knobs, MOCK_RCCL_TIMEOUT_S="4"))
+    R = [np.load(out + ".rank%d.npz" % r) for r in range(world)]
+    from welding_robot_amd._lib import STATUS
+    code = {v: k for k, v in STATUS.items()}
+    for r in range(world):
+        assert R[r]["errs"].tolist() == [code["WA_ERR_ALLOC"], code["WA_ERR_ALLOC"]], (r, R[r]["errs"])
+        assert R[r]["after"].tolist() == [float(sum(range(world)))]
+        assert R[r]["vec"].tolist() == [1.0 + q for q in range(world)]
+        assert int(R[r]["n_got"][0]) == (world if r == 0 else 0)
+        if r != world - 1:
+            assert int(R[r]["dead_code"][0]) == code["WA_ERR_DEVICE"] and 0 < float(R[r]["t_dead"][0]) < 30, (r, R[r]["t_dead"], R[r]["dead_code"])
+            assert int(R[r]["ab"][0]) == code["WA_ERR_STATE"]
 
 
 @pytest.mark.parametrize("world", [2, 3])

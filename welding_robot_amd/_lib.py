@@ -89,6 +89,8 @@ SYMBOLS = {
     "wa_comm_create": (C.c_int, [_V, _I, _I, _P, C.POINTER(_V)]),
     "wa_comm_destroy": (None, [_V]),
     "wa_comm_info": (C.c_int, [_V, _P, _P]),
+    "wa_comm_abort": (C.c_int, [_V]),
+    "wa_comm_stats": (C.c_int, [_V, _P]),
     "wa_acs_allreduce_best": (C.c_int, [_V, _V, _I, _I]),
     "wa_comm_read_best": (C.c_int, [_V, _I, _I, _P]),
     "wa_comm_read_best_owner": (C.c_int, [_V, _I, _I, _P, _P, _P]),

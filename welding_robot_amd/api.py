@@ -409,6 +409,16 @@ class Comm:
     def __del__(self):
         self.close()
 
+    def abort(self):
+        """give the communicator up now (wa_comm_abort -> ncclCommAbort): every later call fails with WA_ERR_STATE"""
+        self.ctx.check(self.ctx.lib.wa_comm_abort(self.h))
+
+    def stats(self):
+        """what RCCL itself says about this communicator, and what was issued on it (wa_comm_stats)"""
+        v = (C.c_int64 * 5)()
+        self.ctx.check(self.ctx.lib.wa_comm_stats(self.h, v))
+        return dict(ranks=int(v[0]), version=int(v[1]), allreduce_calls=int(v[2]), other_calls=int(v[3]), aborted=bool(v[4]))
+
     def allreduce_best(self, solver, gen0, count):
         """asynchronous: MIN over ranks (and active slots) of best_L[gen0 .. gen0+count)"""
         self.ctx.check(self.ctx.lib.wa_acs_allreduce_best(solver.h, self.h, gen0, count))

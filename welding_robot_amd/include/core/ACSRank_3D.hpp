@@ -481,6 +481,17 @@ private:
         return colony < 1 ? 1 : colony;
     }
     bool lazy_ok(int colony) const { return lazy && rng_mode == WA_RNG_DEV && colony <= 2048 && (int)(0.2 * colony) + 1 <= 64; }   // (6 or 26 neighbours: wa_acs_create_lazy_nb)
+    // ... and where it pays.  Measured (round 6, tools/lazy_crossover.py -> profiles/r06/lazy_crossover.txt: 24-ant pair planning, 150 generations,
+    // 32^3 .. 256^3, 1 .. 21 concurrent searches, seconds per plan dense / lazy): the lazy field wins from three searches on at every size (0.44-0.58 x at
+    // three, 0.07 x for 21 searches at 256^3) and for a lone search from 128^3 on (0.96 x; 192^3 0.67, 256^3 0.42); a LONE search on a grid of up to
+    // 64^3 is where the dense sweep is cheaper than the lazy walk's stamp loads (1.22 x).  (Rounds 2-5 took the lazy field whenever it was allowed.)
+    bool lazy_for(int colony, int64_t n_searches)
+    {
+        if (!lazy_ok(colony)) return false;
+        int32_t dims[3] = {0, 0, 0};
+        if (n_searches <= 1 && wa_grid_info(device_grid(), dims, NULL, NULL, NULL) == WA_OK && (int64_t)dims[0] * dims[1] * dims[2] <= ((int64_t)1 << 19)) return false;
+        return true;
+    }
     // Concurrent pair searches of a shard with `n_pairs` searches.  Upper bound from memory: 3/4 of what the device has free
     // (ctx == NULL: the primary context), and never more than ~200 GB of fields -- past that footprint the walk's random record
     // loads slow down (measured on BASELINE config C5: 224 slots of 0.85 GB run 2 016 searches in 0.57 s, 252 in 1.0 s).  The
@@ -493,7 +504,8 @@ private:
         if (!ctx) ctx = weldacs_dropin::context();
         const int colony = colony_of(predict);
         int64_t per_slot = 0, per_field = 0, fixed = 0, free_b = 0, total_b = 0;
-        if (wa_acs_memory_estimate(device_grid(), colony, 0, neighbourhood, lazy_ok(colony) ? 1 : 0, &per_slot, &per_field, &fixed) != WA_OK ||
+        const bool lz = lazy_for(colony, n_pairs);
+        if (wa_acs_memory_estimate(device_grid(), colony, 0, neighbourhood, lz ? 1 : 0, &per_slot, &per_field, &fixed) != WA_OK ||
             wa_ctx_memory_info(ctx, &free_b, &total_b) != WA_OK || per_slot <= 0) return std::min(16, n_pairs);
         per_slot += 20 * (int64_t)max_iteration;                      // the per-generation trace
         std::vector<int> ends;
@@ -508,7 +520,7 @@ private:
         // small dense solvers also hold straggler pools per slot (wa_acs_straggler_pool_bytes; none for lazy or > 16 slots)
         while (cap > 1) {
             int64_t pools = 0;
-            if (wa_acs_straggler_pool_bytes(device_grid(), (int32_t)std::min<int64_t>(cap, n_pairs), colony, 0, neighbourhood, lazy_ok(colony) ? 1 : 0, &pools) != WA_OK ||
+            if (wa_acs_straggler_pool_bytes(device_grid(), (int32_t)std::min<int64_t>(cap, n_pairs), colony, 0, neighbourhood, lz ? 1 : 0, &pools) != WA_OK ||
                 pools <= budget - cap * per_slot) break;
             cap--;
         }
@@ -523,7 +535,7 @@ private:
         // shard's size)
         const int want = rng_mode == WA_RNG_REF ? 1 : (slots_override > 0 ? slots_override : std::max(1, concurrent_pairs));
         if (ctx == weldacs_dropin::context()) slots = want;
-        int rc = lazy_ok(colony) ? wa_acs_create_lazy_nb(ctx, g, want, colony, 0, neighbourhood, out) : wa_acs_create_nb(ctx, g, want, colony, 0, neighbourhood, out);
+        int rc = lazy_for(colony, want) ? wa_acs_create_lazy_nb(ctx, g, want, colony, 0, neighbourhood, out) : wa_acs_create_nb(ctx, g, want, colony, 0, neighbourhood, out);
         if (rc == WA_OK) rc = wa_acs_init_pheromone(*out, -1, 1.0f);
         return rc;
     }
