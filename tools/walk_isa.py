@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from welding_robot_amd import build  # noqa: E402
 
-KERNEL = "_Z10k_walk_devILb1ELb0ELb1ELb0EEv8WaAcsDev5WaRuniii"   # k_walk_dev<alpha 1, dense, touch loads, no rejoin watch>
+KERNEL = "_Z10k_walk_devILb1ELb0ELb1ELb0ELb0EEv8WaAcsDev5WaRuniii"   # k_walk_dev<alpha 1, dense, touch loads, no rejoin watch, look-ahead>
 
 
 def main():
