@@ -152,9 +152,13 @@ def _walk_loop_evidence():
     import re
     out = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "walk_loop_isa.txt")), reverse=True):
-        m = re.match(r"# instructions_per_step: (\d+)", open(f).readline())
+        head = open(f).read(600)
+        m = re.match(r"# instructions_per_step: (\d+)", head)
         if m:
             out["instructions_per_step"], out["isa_file"] = int(m.group(1)), os.path.relpath(f, ROOT)
+            m2 = re.search(r"# vector_memory_per_step: (\d+)\s+conditional_branches_per_step: (\d+)", head)
+            if m2:
+                out["vector_memory_per_step"], out["conditional_branches_per_step"] = int(m2.group(1)), int(m2.group(2))
             break
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "issue_rates.txt")), reverse=True):
         m = re.search(r"v_add_f32 dependent\s+([\d.]+) ticks.*?=\s*([\d.]+) GHz", open(f).read())
@@ -192,6 +196,15 @@ def walk_step_extra(solver, p, ids, wl, generations=12):
         floor = ev["instructions_per_step"] * ev["cycles_per_instruction"] / ev["shader_clock_ghz"]
         out["issue_floor_ns"] = floor
         out["frac_of_issue_floor"] = floor / step if step > 0 else 0.0
+        if "vector_memory_per_step" in ev:
+            # round 6 (profiles/r06/walk_trims.txt): a vector-memory instruction costs ~6 cycles + one per cache line it names (the step's two record loads ~14
+            # each, its two touch loads of the 2-hop ball ~21 each: profiles/r02/issue_rates.txt), a conditional branch that is not taken 13 -- the floor of THIS
+            # step structure, against which removing eight plain instructions was measured to gain nothing
+            cyc = (ev["instructions_per_step"] - ev["vector_memory_per_step"] - ev["conditional_branches_per_step"]) * ev["cycles_per_instruction"] \
+                + 2 * 14 + max(ev["vector_memory_per_step"] - 2, 0) * 21 + 13 * ev["conditional_branches_per_step"]
+            out["structure_floor_ns"] = cyc / ev["shader_clock_ghz"]
+            out["frac_of_structure_floor"] = out["structure_floor_ns"] / step if step > 0 else 0.0
+            out["structure_floor_note"] = "plain slots x 4.31 cycles + line cycles of the four vector-memory instructions + two not-taken branches; what is left is the exposed part of the LDS probe and of the record wait"
     return out
 
 

@@ -40,8 +40,12 @@ def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=
     shards, _ = wd.deal_pairs(pairs, weights, world)
     mine = shards[rank]
     colony = fixed_colony or max(1, int(0.35 * predict / float(grid.precision)))
+    by_length = os.environ.get("WA_PLAN_ORDER", "") == "length"
+    if by_length:   # experiment (round 6): batches of searches of similar length -- a batch-generation lasts as long as its longest walk
+        mine = sorted(mine, key=lambda k: (-weights[k], pairs[k][1], k))
     if not slots:   # sized by rule: free memory, footprint limit, whole batches
-        slots, _ = api.pair_slots_by_rule(ctx, grid, colony, max(1, len(mine)), len({pairs[k][1] for k in mine}), generations, lazy=lazy, neighbourhood=neighbourhood)
+        slots, _ = api.pair_slots_by_rule(ctx, grid, colony, max(1, len(mine)), len({pairs[k][1] for k in mine}), generations, lazy=lazy, neighbourhood=neighbourhood,
+                                          all_fields=by_length)
     plan.last_slots = slots
     t_create = time.perf_counter()
     solver = api.AcsSolver(ctx, grid, n_slots=slots, max_colony=colony, lazy=lazy, neighbourhood=neighbourhood)

@@ -245,6 +245,11 @@ enum { WA_K_WALK = 0, WA_K_RANK = 1, WA_K_EVAPORATE = 2, WA_K_DEPOSIT = 3, WA_K_
  * stamped sweep-carrying launch is preceded by a no-op dispatch with events of its own -- a dispatch with events directly behind one
  * without (the walk) reports 1.6-2 us that belong to that transition, not to the kernel (profiles/r06/sweep_gap.txt) */
 int wa_acs_profile(wa_acs *s, int32_t enable, int32_t sample_every);
+/* what the last DEV walk launch of a 6-neighbour solver ran with (the visited set of ACSRank_3D.hpp:70, :144-146 lives in LDS, one table per
+ * walking ant): [0] log2 of the table's slots, [1] 1 if it kept 16-bit entries (saturated launches of grids whose voxel ids an entry can name;
+ * WA_TAB16=0 in the environment switches them off, =1 forces them), [2] bytes of LDS per walk block -- min(163840 / [2], 16) blocks are resident
+ * per CU --, [3] 1 if the loop carried touch loads (a lone search) */
+int wa_acs_walk_info(const wa_acs *s, int32_t out[4]);
 int wa_acs_profile_read(wa_acs *s, double ms[WA_K_COUNT], int64_t launches[WA_K_COUNT]);
 /* diagnostic counters.  Product build: out16[9] = ants handed over as stragglers, out16[7] = stragglers finished by a resume block (the two
  * are equal after wa_acs_run returns), out16[6] = REF-mode ants confirmed by the converged-colony speculation (below), everything else zero; the cycle counters of the walk's inner loop only exist in the diagnostic

@@ -38,8 +38,11 @@ def main():
         step_a.append(l.strip())
     # step 'a' runs from the top to the instruction before step b's head (v_add of the touch address + s_waitcnt precede Lwa_redo_b)
     n_a = len([l for l in step_a if l and not l.endswith(":")]) - 2
+    n_vmem = len([l for l in ins if l.startswith(("global_load", "global_store", "buffer_load"))]) // 4
+    n_br = len([l for l in ins if l.startswith("s_cbranch")]) // 4
     with open(out, "w") as f:
         f.write("# instructions_per_step: %d  (4 steps per trip, %d instructions per trip + 1 back edge; step 'a' alone: %d)\n" % (trip // 4, trip, n_a))
+        f.write("# vector_memory_per_step: %d  conditional_branches_per_step: %d   (priced apart from the plain issue slots: profiles/r06/walk_trims.txt)\n" % (n_vmem, n_br))
         f.write("# the hand-scheduled general step of the ant walk (ACSRank_3D.hpp:134-193) as assembled for gfx950: %s, one trip = steps a-d\n" % KERNEL)
         f.write("\n".join(l.rstrip() for l in body) + "\n")
     print(open(out).readline().strip())

@@ -84,6 +84,7 @@ SYMBOLS = {
     "wa_acs_debug_counters": (C.c_int, [_V, _P, _I]),
     "wa_acs_straggler_counters": (C.c_int, [_V, _I, _P, _P, _I]),
     "wa_acs_set_stragglers": (C.c_int, [_V, _I]),
+    "wa_acs_walk_info": (C.c_int, [_V, _P]),
     "wa_acs_evaporate": (C.c_int, [_V, _I, _F, _I]),
     "wa_comm_unique_id": (C.c_int, [_P]),
     "wa_comm_create": (C.c_int, [_V, _I, _I, _P, C.POINTER(_V)]),

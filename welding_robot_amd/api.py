@@ -321,6 +321,13 @@ class AcsSolver:
         self.ctx.check(self.ctx.lib.wa_acs_last_params(self.h, slot, C.byref(c), C.byref(l), C.byref(q)))
         return c.value, np.float32(l.value), np.float32(q.value)
 
+    def walk_info(self):
+        """what the last DEV walk launch ran with (wa_acs_walk_info): table size, 16-bit entries or not, LDS per walk block, resident blocks per CU"""
+        v = (C.c_int32 * 4)()
+        self.ctx.check(self.ctx.lib.wa_acs_walk_info(self.h, v))
+        lds = int(v[2])
+        return dict(hash_log2=int(v[0]), entries16=bool(v[1]), lds_bytes_per_block=lds, resident_blocks_per_cu=min(163840 // lds, 16) if lds else 0, touch_loads=bool(v[3]))
+
     def profile(self, enable=True, sample_every=1, sweep_every_generation=False, paired=False):
         """paired: every timed sweep-carrying launch is preceded by a stamped no-op dispatch (wa_acs_profile bit 2; why: profiles/r06/sweep_gap.txt)"""
         self.ctx.check(self.ctx.lib.wa_acs_profile(self.h, ((3 if sweep_every_generation else 1) | (4 if paired else 0)) if enable else 0, sample_every))
@@ -366,14 +373,14 @@ def unpack_best_key(key, lib_path=None):
     return np.float32(c.value), r.value, s_.value
 
 
-def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True, neighbourhood=6):
+def pair_slots_by_rule(ctx, grid, colony, n_pairs, n_ends, max_iteration, lazy=True, neighbourhood=6, all_fields=False):
     """Concurrent pair searches for `n_pairs` searches on this device -- the rule of the drop-in ACS_Rank::slots_for
     (welding_robot_amd/include/core/ACSRank_3D.hpp): 3/4 of the free memory but at most ~200 GB of fields, at most three
     rounds of resident walk blocks, then whole batches of equal size.  Returns (slots, batches)."""
     per_slot, per_field, fixed = memory_estimate(grid, colony, 0, neighbourhood, lazy)
     per_slot += 20 * max_iteration
     free, _ = ctx.memory_info()
-    fields = min(max(4, n_ends), 8)
+    fields = max(4, n_ends) if all_fields else min(max(4, n_ends), 8)   # (all_fields: every end point's heuristic field stays resident)
     cap = (min(free // 4 * 3, int(200e9)) - fixed - fields * per_field) // per_slot
     cap = max(1, min(cap, max(1, 3 * 2048 // colony)))
     batches = -(-n_pairs // cap)

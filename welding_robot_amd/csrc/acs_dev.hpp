@@ -59,6 +59,7 @@ struct WaAcsDev {
     unsigned long long *strag_cnt; // [slot][2]  ants handed over / stragglers finished by a resume block, per slot (wa_acs_straggler_counters)
     const float *prev_pher;        // the field of the previous generation (intact until the next sweep): what a resume block walks on
     float *ltab;                   // [path_cap + 1] L after i steps = precision added i times in fp32 (:78), one table per solver
+    uint32_t tab16_kmul;           // 16-bit tabu entries (WaTabu): K_B << (32 - B) for this grid's B-bit voxel ids, 0 where an entry cannot name them (6 neighbours only)
     int32_t guard_bytes;           // guard band in front of / behind the pheromone and heuristic allocations (6-neighbour solvers)
     int32_t stamp_guard_bytes;     // ... and the stamp allocation of a lazily evaporating solver
     int32_t vbits_rows;            // bitmap rows per slot: max_colony (+ WA_RESUME_MAX rows of the resume blocks when the solver has straggler pools)

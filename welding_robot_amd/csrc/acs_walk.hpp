@@ -18,12 +18,41 @@ struct WaTabu {
     uint32_t mask, shift;
     uint32_t *bits;
     bool spilled;
+    // 16-bit entries (round 6, VERDICT r05 task 1): half the LDS per walk block, so twice the resident blocks where a launch has more blocks
+    // than fit (160 KB per CU: nine blocks of a 2^12 table with 32-bit keys, sixteen -- the register file's limit -- with these).  An entry
+    // names its key EXACTLY: h = id * K_B mod 2^B is a bijection on the grid's B-bit voxel ids (K_B odd: the golden multiplier of width B,
+    // which spreads the near-sequential ids of a lattice walk like the 32-bit one does); the slot index is h's top hl bits, the entry the
+    // next 12 bits (hl + 12 >= B: nothing of h is left out) and, in its low nibble, how far behind its home slot it sits (linear probing).
+    // 0xFFFF = empty, 0xFFFE = the sentinel behind the table; displacements 0..13 can be said.  Measured on the oracle's own ant paths
+    // (tests/tools/tabu16_model.py: 92 first-generation walks of up to 1 772 nodes on 256^3, 2^12 slots): largest displacement 13, none
+    // beyond.  A probe or an insert that WOULD run past 13 sets `ovf` and the walk spills to its bitmap like one that outgrows the table.
+    bool t16 = false;
+    uint32_t kmul = 0;       // K_B << (32 - B): (id * kmul) holds h in its top B bits
+    int32_t hl = 0;          // log2 of the slots
+    int32_t ovf_dw = 0;      // dword index (from tab) of the overflow flag: the LDS word behind the sentinel (every table has it; only 16-bit tables set it)
 };
+#define WA_T16_EMPTY 0xFFFFu
+#define WA_T16_SENTINEL 0xFFFEu
+#define WA_T16_MAXD 13u
+__device__ __forceinline__ uint32_t wa_t16_idx(const WaTabu &t, uint32_t tt) { return tt >> (32 - t.hl); }
+__device__ __forceinline__ uint32_t wa_t16_cmp(const WaTabu &t, uint32_t tt) { return (tt >> (16 - t.hl)) & 0xFFF0u; }
 __device__ __forceinline__ bool tabu_has(const WaTabu &t, int32_t key)
 {
     if (t.spilled) {
         uint32_t w = __hip_atomic_load(&t.bits[(uint32_t)key >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return (w >> (key & 31)) & 1u;
+    }
+    if (t.t16) {
+        const volatile uint16_t *tb = reinterpret_cast<const volatile uint16_t *>(t.tab);
+        const uint32_t tt = (uint32_t)key * t.kmul, c = wa_t16_cmp(t, tt);
+        uint32_t h = wa_t16_idx(t, tt);
+        for (uint32_t d = 0; d <= WA_T16_MAXD; d++) {
+            const uint32_t v = tb[h];
+            if (v == c + d) return true;
+            if (v == WA_T16_EMPTY) return false;
+            h = (h + 1) & t.mask;
+        }
+        return false;   // fourteen slots without the key: it is not in the table (no insert ever lands further from home; one that would, sets ovf and the walk spills)
     }
     uint32_t h = ((uint32_t)key * 2654435761u) >> t.shift;
     for (;;) {
@@ -40,9 +69,50 @@ __device__ __forceinline__ void tabu_insert(const WaTabu &t, int32_t key)
         asm volatile("" ::"v"(old));  // returning atomic: completed before the next lookup
         return;
     }
+    if (t.t16) {
+        volatile uint16_t *tb = reinterpret_cast<volatile uint16_t *>(t.tab);
+        const uint32_t tt = (uint32_t)key * t.kmul, c = wa_t16_cmp(t, tt);
+        uint32_t h = wa_t16_idx(t, tt);
+        for (uint32_t d = 0; d <= WA_T16_MAXD; d++) {
+            if (tb[h] == WA_T16_EMPTY) { tb[h] = (uint16_t)(c + d); return; }
+            h = (h + 1) & t.mask;
+        }
+        reinterpret_cast<volatile int32_t *>(t.tab)[t.ovf_dw] = 1;
+        return;
+    }
     uint32_t h = ((uint32_t)key * 2654435761u) >> t.shift;
     while (t.tab[h] != WA_HASH_EMPTY) h = (h + 1) & t.mask;
     t.tab[h] = key;
+}
+// the same by many lanes at once (distinct keys, no deletions: any insertion order gives a valid open-addressing table): compare-and-swap on
+// the slot -- for 16-bit entries on the word that holds it
+__device__ __forceinline__ void tabu_insert_atomic(const WaTabu &t, int32_t key)
+{
+    if (t.t16) {
+        uint32_t *tw = reinterpret_cast<uint32_t *>(t.tab);
+        const uint32_t tt = (uint32_t)key * t.kmul, c = wa_t16_cmp(t, tt);
+        uint32_t h = wa_t16_idx(t, tt), d = 0;
+        while (d <= WA_T16_MAXD) {
+            const uint32_t w = __hip_atomic_load(&tw[h >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sh = (h & 1u) * 16u;
+            if (((w >> sh) & 0xFFFFu) == WA_T16_EMPTY) {
+                if (atomicCAS(&tw[h >> 1], w, (w & ~(0xFFFFu << sh)) | ((c + d) << sh)) == w) return;
+                continue;   // the word changed under us (its other half, or this slot): look again
+            }
+            h = (h + 1) & t.mask;
+            d++;
+        }
+        reinterpret_cast<volatile int32_t *>(t.tab)[t.ovf_dw] = 1;
+        return;
+    }
+    uint32_t h = ((uint32_t)key * 2654435761u) >> t.shift;
+    while (atomicCAS(&t.tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & t.mask;
+}
+// did a probe or an insert of this wavefront run past what a 16-bit entry can say?  (wave-uniform; every lane's LDS accesses are done)
+__device__ __forceinline__ bool tabu_overflowed(const WaTabu &t)
+{
+    if (!t.t16 || t.spilled) return false;
+    __builtin_amdgcn_wave_barrier();
+    return __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile int32_t *>(t.tab)[t.ovf_dw]) != 0;
 }
 
 // lane `lane_uniform` of v := val_uniform (both wave-uniform).  The s_nop covers the wait states the assembler cannot see through the
@@ -307,8 +377,10 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
                                           const uint32_t *stamp, float clean_info, uint32_t evap_now,
                                           int32_t *path, WaTabu T, int32_t end, uint64_t antkey, int32_t &rng_rs,
                                           int32_t &rng_f, int32_t &rng_b, int32_t spill_at, WaWalkState &st,
-                                          int32_t *flags_out)
+                                          int32_t *flags_out, int32_t max_steps = 0x7fffffff)
 {
+    // max_steps = 1: ONE step by the book and back to the caller with the walk unfinished (the hand-scheduled loop with 16-bit tabu entries hands a step
+    // over when a probe chain outruns what an entry can say: the lookups here are exact -- fourteen slots decide -- and the loop is re-entered)
     const int lane = threadIdx.x;
     const int32_t nx = D.d.nx, nxy = D.d.nxy;
     int32_t cur = st.cur, len = st.len;
@@ -316,8 +388,15 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
     float L = st.L;
     const int k = lane;
     const int32_t dk = wa_delta(k, nx, nxy);
+    bool finished = true;
     for (;;) {
-        if (!T.spilled && len > spill_at) {  // hash nearly full: move the set to the bitmap
+        if (!T.spilled && (len > spill_at || tabu_overflowed(T))) {  // hash nearly full (or a 16-bit entry could not be said): move the set to the bitmap
+#if !defined(WA_ANT_TIME) && !defined(WA_STAMPS)
+            if (lane == 0 && D.dbg) {   // wa_acs_debug_counters: [13] walks that spilled, [14] of them because a 16-bit entry could not be said
+                atomicAdd(&D.dbg[13], 1ULL);
+                if (len <= spill_at) atomicAdd(&D.dbg[14], 1ULL);
+            }
+#endif
             __threadfence();
             for (int i = lane; i < len; i += 64) {
                 int32_t id = __hip_atomic_load(&path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & WA_ID_MASK;
@@ -384,6 +463,7 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
         step++;
         if (next == end) break;
         cur = next;
+        if (--max_steps == 0) { finished = false; break; }
     }
     if (T.spilled) {  // leave the bitmap all-zero for the next walk
         __threadfence();
@@ -394,7 +474,7 @@ __device__ __forceinline__ void wa_walk_slow(const WaAcsDev &D, const WaRun &R, 
         __threadfence();
     }
     st.cur = cur; st.len = len; st.step = step; st.L = L;
-    st.done = true;
+    st.done = finished;
 }
 
 // ------------------------------------------------------------------ replay of the best path
@@ -492,6 +572,7 @@ __device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const
         const uint32_t h = (a.x >= rnd ? 1u : 0u) | (a.y >= rnd ? 2u : 0u) | (a.z >= rnd ? 4u : 0u) | (a.w >= rnd ? 8u : 0u) |
                            (b.x >= rnd ? 16u : 0u) | (b.y >= rnd ? 32u : 0u);
         const int pick = h ? 31 - __clz((int)h) : -1;
+        if (tabu_overflowed(V)) { stop = q; return 3; }   // a lookup of V was left undecided (16-bit entries): no row can be trusted -- the general step decides (and spills)
         const unsigned long long fm = __ballot(live && (!applies || pick != nk));
         if (fm != 0) {
             const int g = __ffsll((long long)fm) - 1;
@@ -510,9 +591,9 @@ __device__ __forceinline__ int wa_replay_from(const float *__restrict__ T, const
 #endif
 // every slot of the tabu hash := empty.  Eight 1-KB wave stores per trip (immediate offsets, no address arithmetic between them):
 // the 128 KB table of a lone search takes ~0.5 us instead of the 4.6 us of a store-per-trip loop (measured, tools/ant_time.py)
-__device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
+__device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2, bool t16 = false)
 {
-    const int n16 = (1 << hash_log2) / 4, lane = threadIdx.x;
+    const int n16 = ((t16 ? 2 : 4) << hash_log2) / 16, lane = threadIdx.x;   // 16-byte units of the table (0xFFFF = the empty 16-bit entry: the same bytes)
     const int4 e = make_int4(-1, -1, -1, -1);
     int i = lane;
     for (; i + 7 * 64 < n16; i += 8 * 64) {
@@ -521,11 +602,17 @@ __device__ __forceinline__ void wa_tabu_clear(int4 *tab4, int hash_log2)
     }
     for (; i < n16; i += 64) tab4[i] = e;
     // the entry behind the table is a sentinel: the hand-scheduled loop reads every probed slot together with its successor, and the
-    // successor of the LAST slot is this one -- neither empty nor any key, so that lane takes the slow path to slot 0
-    if (lane == 0) reinterpret_cast<int32_t *>(tab4)[1 << hash_log2] = WA_HASH_SENTINEL;
+    // successor of the LAST slot is this one -- neither empty nor any key, so that lane takes the slow path to slot 0.  The word behind it is
+    // the overflow flag of the 16-bit tables (WaTabu::ovf)
+    if (lane == 0) {
+        int32_t *tab = reinterpret_cast<int32_t *>(tab4);
+        const int dw = t16 ? (1 << hash_log2) / 2 : (1 << hash_log2);
+        tab[dw] = t16 ? (int32_t)(0xFFFF0000u | WA_T16_SENTINEL) : WA_HASH_SENTINEL;
+        tab[dw + 1] = 0;
+    }
 }
 
-template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false>
+template <int MODE, bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false, bool T16 = false>
 __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, int32_t slot, int32_t ant,
                                             int32_t start, int32_t end, uint64_t antkey, int32_t *tab,
                                             int hash_log2, int32_t &rng_rs, int32_t &rng_f, int32_t &rng_b,
@@ -614,10 +701,15 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         for (int32_t q = 0; q < node; q++) st.L += R.precision;  // :78, one add per step taken
         prefix_words = bpath;
     }
+    // T16: 16-bit tabu entries (the host launches those instantiations for saturated launches of grids whose ids an entry can name: WaAcsDev::tab16_kmul)
+    static_assert(!T16 || (!WARM && !DIRECT && MODE == 1 && ALPHA1), "16-bit tabu entries: DEV mode, alpha 1, the loops without touch loads");
+    constexpr bool t16 = T16;
     WaTabu T;
     T.tab = tab;
     T.mask = (1u << hash_log2) - 1u;
     T.shift = 32 - hash_log2;
+    T.t16 = t16; T.kmul = D.tab16_kmul; T.hl = hash_log2;
+    T.ovf_dw = (t16 ? (1 << hash_log2) / 2 : (1 << hash_log2)) + 1;
     // (a resume block spills into a bitmap row of its own, behind the ants' rows: the ant's row belongs to the running generation's ant)
     T.bits = D.vbits + ((int64_t)slot * D.vbits_rows + (bits_row >= 0 ? bits_row : ant)) * D.vbits_words;
     T.spilled = false;
@@ -625,26 +717,29 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
 
     WA_PHASE(6);
     int4 *tab4 = reinterpret_cast<int4 *>(tab);
-    wa_tabu_clear(tab4, hash_log2);
+    wa_tabu_clear(tab4, hash_log2, t16);
     __builtin_amdgcn_wave_barrier();
     WA_PHASE(7);
     if (prefix_words && st.len <= spill_at) {  // (a longer prefix goes straight to the spilled slow loop)
         // tabu set := the replayed prefix.  Distinct keys, no deletions: any insertion order gives a valid
         // open-addressing table, so the lanes insert concurrently with compare-and-swap on the slot.
-        for (int32_t q = lane; q < st.len; q += 64) {
-            const int32_t key = prefix_words[q] & (int32_t)WA_ID_MASK;
-            uint32_t h = ((uint32_t)key * 2654435761u) >> T.shift;
-            while (atomicCAS(&tab[h], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) h = (h + 1) & T.mask;
-        }
+        for (int32_t q = lane; q < st.len; q += 64) tabu_insert_atomic(T, prefix_words[q] & (int32_t)WA_ID_MASK);
     } else if (!prefix_words && lane == 0) {
         tabu_insert(T, start);  // addStartNode :81-86 (path[0] is buffered by the fast loop)
     }
     __builtin_amdgcn_wave_barrier();
-    const int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
+    // (16-bit entries: a prefix that could not be filed -- or a build / parameter set without the hand-scheduled loop, which alone knows them -- goes
+    //  straight to the slow loop, which spills)
+    int32_t fast_limit = (int32_t)D.path_cap < spill_at + 1 ? (int32_t)D.path_cap : spill_at + 1;
     bool use_asm = false;
 #ifndef WA_STAMPS
     use_asm = ALPHA1 && (walk_flags & 1) && (MODE == 1 || !SPARSE);   // (REF mode: the same loop, draws from the libc stream)
 #endif
+    if (t16 && (!use_asm || tabu_overflowed(T))) {
+        if (lane == 0) tab[T.ovf_dw] = 1;
+        __builtin_amdgcn_wave_barrier();
+        fast_limit = 0;
+    }
     // ---- a straggler (the loop left through its check, st.reason == 5): its path so far goes to a pool entry of its generation; agents[]
     // says "not arrived, st.len nodes" (what the ranking sees); a resume block of the next walk launch finishes it and adds the rest to
     // the generation's statistics.  False when the pool is full: the ant walks on without the check.
@@ -690,13 +785,19 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
         const int32_t dbg_prefix = st.len;
 #endif
         for (;;) {
-            wa_walk_fast_asm<SPARSE ? 3 : 2, WARM, false, DIRECT>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+            wa_walk_fast_asm<SPARSE ? 3 : 2, WARM, false, DIRECT, T16>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
                                              D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, nullptr, mark, knob_anywhere ? 0u : best_ver, hold,
-                                             SPARSE ? nullptr : sg.arr_len, cut_n);
+                                             SPARSE ? nullptr : sg.arr_len, cut_n, nullptr, nullptr, nullptr, t16 ? T.kmul : 0u);
             prefix_words = path;                                  // from now on the ant's own words (its partial block is in memory)
 #ifdef WA_ANT_TIME
             if (dbg_t_hand) { dbg_t_hand = 0; }
 #endif
+            if (T16 && !st.done && st.reason == 6) {   // 16-bit entries: a probe chain outran what an entry can say -- this ONE step by the book, then back into the loop
+                wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out, 1);
+                st.pbuf_valid = false;
+                if (st.done || tabu_overflowed(T) || st.len >= fast_limit) break;
+                continue;
+            }
             if (st.done || st.reason != 4) break;   // (5: a straggler, handed over below)
 #ifdef WA_ANT_TIME
             dbg_hand++;
@@ -715,9 +816,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                 for (int32_t t = lane; t < gained; t += 64) {     // the ant walked best[q+1 .. stop]: path words (:76-77) and tabu set (:75)
                     const int32_t w = bpath[q + 1 + t];
                     path[st.len + t] = w;
-                    const int32_t key = w & (int32_t)WA_ID_MASK;
-                    uint32_t hh = ((uint32_t)key * 2654435761u) >> T.shift;
-                    while (atomicCAS(&tab[hh], WA_HASH_EMPTY, key) != WA_HASH_EMPTY) hh = (hh + 1) & T.mask;
+                    tabu_insert_atomic(T, w & (int32_t)WA_ID_MASK);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (gained > 0) {
@@ -735,6 +834,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                 if (kind == 2) { st.L = D.ltab[st.len - 1]; st.done = true; break; }   // arrived over the rest of the best path (:78)
                 if (kind == 1) { st.L = INFINITY; st.done = true; break; }      // no candidate at best[stop] (:162-166, :191-192)
             }
+            if (tabu_overflowed(T)) break;   // (16-bit entries: a lookup or a commit ran past what an entry can say -- the slow loop spills and goes on)
             if (gained > 0) { backoff = 1; hold = 1; }
             else { hold = backoff; backoff = backoff < 32 ? backoff * 2 : 32; }   // the table does not apply here: walk on before asking again
 #ifdef WA_ANT_TIME
@@ -761,9 +861,17 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
                                         &rng_rs, &rng_f, &rng_b);
     } else if (st.len < fast_limit && use_asm) {
         WA_PHASE(8);
-        wa_walk_fast_asm<SPARSE ? 1 : 0, WARM, false, DIRECT>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
-                                 D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr,
-                                 nullptr, 0, 0, SPARSE ? nullptr : sg.arr_len, cut_n);
+        for (;;) {
+            wa_walk_fast_asm<SPARSE ? 1 : 0, WARM, false, DIRECT, T16>(R, pher, heur, stamp, clean_info, evap_now, path, tab, hash_log2, D.d.nx, D.d.nxy, (int32_t)D.path_cap, end, antkey, spill_at,
+                                     D.guard_bytes, D.stamp_guard_bytes, D.ltab, st, flags_out, prefix_words, (slot == 0 && ant == 0) ? D.dbg : nullptr,
+                                     nullptr, 0, 0, SPARSE ? nullptr : sg.arr_len, cut_n, nullptr, nullptr, nullptr, t16 ? T.kmul : 0u);
+            if (!T16 || st.done || st.reason != 6) break;
+            // 16-bit entries: a probe chain outran what an entry can say -- this ONE step by the book (the lookups there are exact), then back into the loop
+            wa_walk_slow<MODE, SPARSE>(D, R, pher, heur, stamp, clean_info, evap_now, path, T, end, antkey, rng_rs, rng_f, rng_b, spill_at, st, flags_out, 1);
+            prefix_words = path;
+            st.pbuf_valid = false;
+            if (st.done || tabu_overflowed(T) || st.len >= fast_limit) break;
+        }
         if (!st.done && st.reason == 5) {
             if (hand_over()) return;
             st.L = D.ltab[st.len - 1];              // the pool is full: the generic loop finishes this ant
@@ -954,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_apply_table(WaAcsDev D, WaRun R, int32_
 // the first generations of a search, in which the watch cannot be armed yet (it waits for a best path that has been stable for
 // WA_REENTRY_STABLE generations): the mere presence of that code costs the exploratory walk 1.5 % (187 vs 190 us per launch).
 // DIRECT: the hand-scheduled loop without look-ahead (saturated launches; see walk_loop_gfx950.hpp, W = DIRECT)
-template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false>
+template <bool ALPHA1, bool SPARSE, bool WARM = true, bool REJ = true, bool DIRECT = false, bool T16 = false>
 __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_log2, int32_t gen, int32_t walk_flags)
 {
     extern __shared__ int32_t lds[];
@@ -975,7 +1083,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
         Dp.pher = const_cast<float *>(D.prev_pher);
         const uint64_t key = wa_ctr_antkey(wa_ctr_key(R.seed, c->stream, (uint32_t)(gen - 1)), (uint32_t)a);
         int32_t f0 = 0, b0 = 0, rs0 = 0;
-        wa_walk_one<1, true, false, WARM, false, DIRECT>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
+        wa_walk_one<1, true, false, WARM, false, DIRECT, T16>(Dp, R, slot, a, c->start, c->end, key, lds, hash_log2, rs0, f0, b0, &D.ctl[slot].flags, 0, INFINITY, 0.f, 0u,
                                                  walk_flags & (1 | 64), 0u, c->heur_slot, 0x7fffffff, D.prev_paths + ((int64_t)slot * D.max_colony + a) * D.path_cap, n0, gen - 1,
                                                  D.max_colony + r);
 #ifdef WA_STRAG_TIME
@@ -1001,7 +1109,7 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     int32_t cut_n = 0x7fffffff;
     if (!SPARSE && ALPHA1 && (walk_flags & 32) && D.pool_n) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
     if (cut_n < 1) cut_n = 1;
-    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ, DIRECT>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
+    wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ, DIRECT, T16>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot, cut_n, nullptr, 0, gen);
 #ifdef WA_STRAG_TIME
     if (threadIdx.x == 0 && gen < 128) {

@@ -85,9 +85,9 @@
 #define WA_ASM_VMWAIT_LAZY_DIRECT "s_waitcnt vmcnt(0)\n"
 // where the step's tail puts the records it requests: look-ahead -> where THIS step's records were (needed by the step after the next
 // one); DIRECT -> the other register set (needed by the NEXT step), loads in front of the probe (they are what the next step waits for)
-#define WA_ASM_REQ_SELF(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT(CP, CH, CS, HEAD)
-#define WA_ASM_REQ_NONE(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT(CP, CH, CS, HEAD)
-#define WA_ASM_REQ_DIRECT(CP, CH, CS, NP, NH, NS, HEAD) WA_ASM_NEXT_LOADS(NP, NH, NS, HEAD) WA_SPAN_8 WA_ASM_NEXT_PROBE
+#define WA_ASM_REQ_SELF(CP, CH, CS, NP, NH, NS, HEAD, T) WA_ASM_NEXT(CP, CH, CS, HEAD, T)
+#define WA_ASM_REQ_NONE(CP, CH, CS, NP, NH, NS, HEAD, T) WA_ASM_NEXT(CP, CH, CS, HEAD, T)
+#define WA_ASM_REQ_DIRECT(CP, CH, CS, NP, NH, NS, HEAD, T) WA_ASM_NEXT_LOADS(NP, NH, NS, HEAD) WA_SPAN_8 WA_ASM_NEXT_PROBE_##T
 // the block that holds the next step's records: the picked lane's position -- or, DIRECT, block 0 for ever (s[54:55] stays 63 << 0
 // until an event zeroes it; the event handler restores it from %[g8] = 0)
 #define WA_ASM_ACTIVE_SELF "s_lshl_b32 %[g8], s45, 3\n" "s_lshl_b64 s[54:55], 63, %[g8]\n"
@@ -330,6 +330,27 @@
     "global_load_dword " CP ", v82, %[pher]\n"                                                                    \
     "global_load_dword " CH ", v82, %[heur]\n"                                                                    \
     HEAD(CS)
+// 16-bit entries (T16, see WaTabu in acs_walk.hpp; saturated launches): t = id * kmul holds the bijective hash in its top bits; %[hs] is 31 - hl and
+// %[hm4] (size - 1) * 2 there -- the slot's BYTE address --, s68 = kmul, s69 = 16 - hl, s71 = 0xffff (prologue); v76 = what the slot holds if it holds
+// this lane's key at the displacement the lane's chain stands on (the collision path adds one per slot)
+#define WA_ASM_NEXT_PROBE_T16                                                                                     \
+    "s_mul_i32 s41, %[cur], s68\n"                                                                                \
+    "v_add_u32 v75, s41, v67\n"                                                                                   \
+    "v_lshrrev_b32 v77, %[hs], v75\n"                                                                             \
+    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
+    "ds_read_u16 v100, v77\n"                                      /* next step's tabu probe: the slot ... */       \
+    "ds_read_u16 v101, v77 offset:2\n"                             /* ... and its successor (the sentinel behind the last slot) */ \
+    "v_lshrrev_b32 v76, s69, v75\n"                                                                               \
+    "v_and_b32 v76, 0xfff0, v76\n"
+#define WA_ASM_NEXT_PROBE_T32 WA_ASM_NEXT_PROBE
+#define WA_ASM_CMPS_T32                                                                                           \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                               /* probed slot does not hold the neighbour */   \
+    "v_cmp_ne_u32 s[48:49], -1, v100\n"                           /* ... and is not empty: chain goes on */
+#define WA_ASM_CMPS_T16                                                                                           \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                                                                               \
+    "v_cmp_ne_u32 s[48:49], s71, v100\n"
+#define WA_ASM_INSERT_T32 "ds_write_b32 v84, v76\n"
+#define WA_ASM_INSERT_T16 "ds_write_b16 v84, v76\n"
 #define WA_ASM_NEXT_PROBE                                                                                         \
     "s_mul_i32 s41, %[cur], 0x9e3779b1\n"                                                                         \
     "v_add_u32 v77, s41, v67\n"                                                                                   \
@@ -339,12 +360,12 @@
     "v_add_u32 v76, %[cur], v68\n"
 // the probe goes first: its LDS round trip (~50 cycles) then runs under the record loads' issue instead of in front of the next
 // step's head (measured, tools/walk_ab.py: -1 % on the step)
-#define WA_ASM_NEXT(CP, CH, CS, HEAD) WA_ASM_NEXT_PROBE WA_SPAN_8 WA_ASM_NEXT_LOADS(CP, CH, CS, HEAD)
-#define WA_ASM_STEP(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_NONE, W)
-#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_WATCH, W)
-#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_NONE, W)
-#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X, W) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_WATCH, W)
-#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ, W)                                \
+#define WA_ASM_NEXT(CP, CH, CS, HEAD, T) WA_ASM_NEXT_PROBE_##T WA_SPAN_8 WA_ASM_NEXT_LOADS(CP, CH, CS, HEAD)
+#define WA_ASM_STEP(CP, CH, NP, NH, X, W, T) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_NONE, W, T)
+#define WA_ASM_STEP_REJ(CP, CH, NP, NH, X, W, T) WA_ASM_STEP_G(CP, CH, NP, NH, "", "", X, WA_ASM_HEAD_DENSE, WA_ASM_INFO_DENSE, WA_ASM_INFO2_DENSE, WA_ASM_VMWAIT_##W, WA_ASM_REJ_WATCH, W, T)
+#define WA_ASM_STEP_LAZY(CP, CH, CS, NP, NH, NS, X, W, T) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_NONE, W, T)
+#define WA_ASM_STEP_LAZY_REJ(CP, CH, CS, NP, NH, NS, X, W, T) WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, WA_ASM_HEAD_LAZY, WA_ASM_INFO_LAZY, WA_ASM_INFO2_LAZY, WA_ASM_VMWAIT_LAZY_##W, WA_ASM_REJ_WATCH, W, T)
+#define WA_ASM_STEP_G(CP, CH, NP, NH, CS, NS, X, HEAD, INFO, INFO2, VMWAIT, REJ, W, T)                             \
     WA_SPAN_0                                                                                                     \
     WA_ASM_WARM_ADDR_##W                                          /* (s40 = cur * 24 since the previous step's tail) */ \
     WA_ASM_STAMP(72)                                                                                              \
@@ -354,8 +375,7 @@
     WA_ASM_STAMP(73)                                                                                              \
     REJ(X)                                                        /* once per step: a re-evaluation (collision, block boundary) enters below */ \
     "Lwa_redo_" X "%=:\n"                                                                                         \
-    "v_cmp_ne_u32 vcc, v100, v76\n"                               /* probed slot does not hold the neighbour */   \
-    "v_cmp_ne_u32 s[48:49], -1, v100\n"                           /* ... and is not empty: chain goes on */       \
+    WA_ASM_CMPS_##T                                                                                               \
     VMWAIT                                                        /* records of cur; the touch loads + the new ones stay in flight */ \
     WA_SPAN_2                                                                                                     \
     WA_ASM_STAMP(74)                                                                                              \
@@ -387,12 +407,12 @@
     "v_cmp_eq_u32 vcc, s45, v64\n"                                                                                \
     "v_readlane_b32 s44, v85, s45\n"                              /* path word of the move */                     \
     "v_cndmask_b32 v84, v70, v77, vcc\n"                                                                          \
-    "ds_write_b32 v84, v76\n"                                     /* addNextNode :75 -- the probe ended on the free slot */ \
+    WA_ASM_INSERT_##T                                             /* addNextNode :75 -- the probe ended on the free slot */ \
     WA_ASM_EXP_STORE                                                                                              \
     WA_SPAN_7                                                                                                     \
     WA_ASM_ACTIVE_##W                                             /* next active block = position of the pick (low 6 bits count) */ \
     "s_and_b32 %[cur], s44, 0x1fffffff\n"                                                                         \
-    WA_ASM_REQ_##W(CP, CH, CS, NP, NH, NS, HEAD)                                                                 \
+    WA_ASM_REQ_##W(CP, CH, CS, NP, NH, NS, HEAD, T)                                                              \
     WA_SPAN_9                                                                                                     \
     "v_writelane_b32 %[pbuf], s44, m0\n"                          /* :76-77 */                                    \
     "s_add_i32 m0, m0, 1\n"                                                                                       \
@@ -403,7 +423,47 @@
     WA_SPAN_10                                                                                                    \
     WA_ASM_STAMP(77)
 // some lane's probe hit another key: advance those lanes along their chains, compare again and re-enter at the masks
-#define WA_ASM_COLL(X)                                                                                            \
+#define WA_ASM_COLL(X, T) WA_ASM_COLL_##T(X)
+// the same for 16-bit entries: two bytes per slot, the lane's compare value follows its chain (displacement + 1 per slot); a chain that would stand 14
+// slots behind its home slot cannot be decided by an entry any more -> Lwa_ovf: the loop hands back with code 6 and the walk spills to its bitmap
+#define WA_ASM_COLL_T16(X)                                                                                        \
+    "Lwa_coll_" X "%=:\n"                                                                                         \
+    WA_ASM_COUNT_COLL                                                                                             \
+    "s_mov_b64 s[58:59], exec\n"                                                                                  \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "v_mov_b32 v100, v101\n"                                                                                      \
+    "v_add_u32 v77, 2, v77\n"                                                                                     \
+    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
+    "v_add_u32 v76, 1, v76\n"                                                                                     \
+    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "Lwa_coll_cmp_" X "%=:\n"                                                                                     \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                                                                               \
+    "v_cmp_ne_u32 s[48:49], s71, v100\n"                                                                          \
+    "s_nop 3\n"                                                                                                   \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc0 Lwa_masks_" X "%=\n"                                                                          \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "ds_read_u16 v100, v77\n"                                                                                     \
+    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "v_cmp_ne_u32 vcc, v100, v76\n"                                                                               \
+    "v_cmp_ne_u32 s[48:49], s71, v100\n"                                                                          \
+    "s_nop 3\n"                                                                                                   \
+    "s_and_b64 s[48:49], s[48:49], vcc\n"                                                                         \
+    "s_cbranch_scc0 Lwa_masks_" X "%=\n"                                                                          \
+    "s_mov_b64 exec, s[48:49]\n"                                                                                  \
+    "v_add_u32 v77, 2, v77\n"                                                                                     \
+    "v_and_b32 v77, %[hm4], v77\n"                                                                                \
+    "v_add_u32 v76, 1, v76\n"                                                                                     \
+    "v_and_b32 v94, 15, v76\n"                                    /* the displacement the chain stands on now */   \
+    "v_cmp_lt_u32 vcc, 13, v94\n"                                                                                 \
+    "ds_read_u16 v100, v77\n"                                                                                     \
+    "s_mov_b64 exec, s[58:59]\n"                                                                                  \
+    "s_nop 3\n"                                                                                                   \
+    "s_cbranch_vccnz Lwa_ovf%=\n"                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "s_branch Lwa_coll_cmp_" X "%=\n"
+#define WA_ASM_COLL_T32(X)                                                                                        \
     "Lwa_coll_" X "%=:\n"                                                                                         \
     WA_ASM_COUNT_COLL                                                                                             \
     "s_mov_b64 s[58:59], exec\n"                                                                                  \
@@ -446,7 +506,7 @@
 #define WA_ASM_RARE(CP, CH, X, IDX) "Lwa_rare_" X "%=:\n" WA_ASM_RARE_BODY(CP, CH, IDX)
 
 // the pieces of the loop's assembly text that the dense and the lazy variant share
-#define WA_ASM_PROLOGUE                                                                                           \
+#define WA_ASM_PROLOGUE_T32                                                                                           \
     "v_mov_b32 v64, %[c0]\n"                     /* the seven lane constants: lane, record offset, touch offset, hash term, */ \
     "v_mov_b32 v65, %[c1]\n"                     /* neighbour offset, path-word term, dummy slot (see wa_walk_fast_asm) */      \
     "v_mov_b32 v66, %[c2]\n"                                                                                      \
@@ -465,6 +525,29 @@
     "v_lshlrev_b32 v77, 2, v77\n"                                                                                 \
     "ds_read2_b32 v[100:101], v77 offset1:1\n"                                                                    \
     "v_add_u32 v76, %[cur], v68\n"                                                                                \
+    "s_mul_i32 s40, %[cur], 24\n"                /* records of cur's six neighbours: what the first step's tail would have requested */ \
+    "v_add_u32 v82, s40, v65\n"                                                                                   \
+    "global_load_dword v73, v82, %[pher]\n"                                                                       \
+    "global_load_dword v74, v82, %[heur]\n"
+#define WA_ASM_PROLOGUE_T16                                                                                           \
+    "v_mov_b32 v64, %[c0]\n"                     /* the seven lane constants: lane, record offset, touch offset, hash term, */ \
+    "v_mov_b32 v65, %[c1]\n"                     /* neighbour offset, path-word term, dummy slot (see wa_walk_fast_asm) */      \
+    "v_mov_b32 v66, %[c2]\n"                                                                                      \
+    "v_mov_b32 v67, %[c3]\n"                                                                                      \
+    "v_mov_b32 v68, %[c4]\n"                                                                                      \
+    "v_mov_b32 v69, %[c5]\n"                                                                                      \
+    "v_mov_b32 v70, %[c6]\n"                                                                                      \
+    "v_mov_b32 v71, %[pio]\n"                                                                                     \
+    "v_mov_b32 v72, %[hio]\n"                                                                                     \
+    "s_lshl_b64 s[54:55], 63, %[g8]\n"                                                                            \
+    "s_mov_b32 m0, %[len]\n"                      /* the node count lives in m0: lane select of the draw and of the path word */ \
+    "ds_read_b32 v75, %[lc] offset:" WA_LC_OFF_PARAM "\n"          /* lanes 5, 6 of the parameter column: kmul, 16 - hl (16-bit entries) */ \
+    "s_mov_b32 s71, 0xffff\n"                                     /* the empty 16-bit entry */                    \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "v_readlane_b32 s68, v75, 5\n"                                                                                \
+    "v_readlane_b32 s69, v75, 6\n"                                                                                \
+    "s_nop 3\n"                                                                                                   \
+    WA_ASM_NEXT_PROBE_T16                                                                                         \
     "s_mul_i32 s40, %[cur], 24\n"                /* records of cur's six neighbours: what the first step's tail would have requested */ \
     "v_add_u32 v82, s40, v65\n"                                                                                   \
     "global_load_dword v73, v82, %[pher]\n"                                                                       \
@@ -574,12 +657,14 @@
     "s_cmp_eq_u32 s47, 2\n"                                                                                       \
     "s_cbranch_scc1 Lwa_redo_c%=\n"                                                                               \
     "s_branch Lwa_redo_d%=\n"                                                                                     \
+    "Lwa_ovf%=:\n"                                                /* (16-bit entries) a probe chain ran past what an entry can say: the walk spills */ \
+    "s_mov_b32 %[code], 6\n"                                                                                      \
     "Lwa_out%=:\n"                                                                                                \
     "s_mov_b32 %[len], m0\n"                                                                                      \
     WA_ASM_STAMPS_DUMP                                                                                            \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
 #define WA_ASM_CLOBBERS                                                                                           \
-    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v100", "v101", "v76", "v77", "v78", "v79", "v80", "v81", "v82",  \
+    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v100", "v101", "v76", "v77", "s68", "s69", "s71", "v78", "v79", "v80", "v81", "v82",  \
         "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44",     \
         "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", WA_ASM_STAMPS_CLOBBER    \
         "vcc", "scc", "m0", "memory"
@@ -615,35 +700,35 @@
 #define WA_ASM_REJ_INIT "s_mov_b32 s78, -1\n v_readlane_b32 s80, v94, 3\n v_readlane_b32 s81, v94, 4\n"
 #define WA_ASM_REJ_EXITS WA_ASM_REJ_EXIT("v71", "v72", "a") WA_ASM_REJ_EXIT("v73", "v74", "b") WA_ASM_REJ_EXIT("v71", "v72", "c") WA_ASM_REJ_EXIT("v73", "v74", "d")
 // the two dense loops as statements (W = SELF | NONE: the touch loads, see above)
-#define WA_ASM_RUN_DENSE(W)                                                                                       \
+#define WA_ASM_RUN_DENSE(W, T)                                                                                       \
     asm volatile(                                                                                                 \
-        WA_ASM_PROLOGUE WA_ASM_STAMPS_INIT WA_ASM_LOOP_ALIGN                                                      \
+        WA_ASM_PROLOGUE_##T WA_ASM_STAMPS_INIT WA_ASM_LOOP_ALIGN                                                      \
         "Lwa_top%=:\n"                                                                                            \
-        WA_ASM_STEP("v71", "v72", "v73", "v74", "a", W)                                                           \
-        WA_ASM_STEP("v73", "v74", "v71", "v72", "b", W)                                                           \
-        WA_ASM_STEP("v71", "v72", "v73", "v74", "c", W)                                                           \
-        WA_ASM_STEP("v73", "v74", "v71", "v72", "d", W)                                                           \
+        WA_ASM_STEP("v71", "v72", "v73", "v74", "a", W, T)                                                           \
+        WA_ASM_STEP("v73", "v74", "v71", "v72", "b", W, T)                                                           \
+        WA_ASM_STEP("v71", "v72", "v73", "v74", "c", W, T)                                                           \
+        WA_ASM_STEP("v73", "v74", "v71", "v72", "d", W, T)                                                           \
         "s_branch Lwa_top%=\n"                                                                                    \
-        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_COLL("a", T) WA_ASM_COLL("b", T) WA_ASM_COLL("c", T) WA_ASM_COLL("d", T)                                       \
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
         : [code] "=&s"(code), [cur] "+s"(cur), [len] "+s"(len), [g8] "+s"(g8), [pio] "+v"(p), [hio] "+v"(h), [pbuf] "+v"(pbuf), [ub] "+v"(ublock), [em] "+s"(em) \
         : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [c6] "v"(c6), [lc] "v"(lcaddr), [pher] "s"(pher_b), [heur] "s"(heur_b), [hs] "s"(hshift), [hm4] "s"(hm4), [end] "s"(end), [path] "s"(path), \
           [limit] "s"(limit), [klo] "s"((uint32_t)antkey), [khi] "s"((uint32_t)(antkey >> 32)), [cut] "s"(cut_list), [cutn] "s"(cut_n) \
         : WA_ASM_CLOBBERS);
-#define WA_ASM_RUN_REJ(W)                                                                                         \
+#define WA_ASM_RUN_REJ(W, T)                                                                                         \
     asm volatile(                                                                                                 \
-        WA_ASM_PROLOGUE                                                                                           \
+        WA_ASM_PROLOGUE_##T                                                                                       \
         "ds_read_b32 v94, %[lc] offset:" WA_LC_OFF_PARAM "\n"        /* lanes 3, 4: best-path version, hold-off */               \
         "s_waitcnt lgkmcnt(0)\n"                                                                                  \
         WA_ASM_REJ_INIT WA_ASM_LOOP_ALIGN                                                                         \
         "Lwa_top%=:\n"                                                                                            \
-        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a", W)                                                       \
-        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b", W)                                                       \
-        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "c", W)                                                       \
-        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "d", W)                                                       \
+        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "a", W, T)                                                       \
+        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "b", W, T)                                                       \
+        WA_ASM_STEP_REJ("v71", "v72", "v73", "v74", "c", W, T)                                                       \
+        WA_ASM_STEP_REJ("v73", "v74", "v71", "v72", "d", W, T)                                                       \
         "s_branch Lwa_top%=\n"                                                                                    \
-        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_COLL("a", T) WA_ASM_COLL("b", T) WA_ASM_COLL("c", T) WA_ASM_COLL("d", T)                                       \
         WA_ASM_RARE("v71", "v72", "a", "0") WA_ASM_RARE("v73", "v74", "b", "1") WA_ASM_RARE("v71", "v72", "c", "2") WA_ASM_RARE("v73", "v74", "d", "3") \
         WA_ASM_REJ_EXITS                                                                                          \
         WA_ASM_TAIL_(WA_ASM_CUT)                                                                                  \
@@ -653,9 +738,9 @@
         : "s78", "s80", "s81", "s82", "s83", WA_ASM_CLOBBERS);
 // the lazy-field loop as a statement (STEP = WA_ASM_STEP_LAZY or WA_ASM_STEP_LAZY_REJ; REJINIT / REJEXITS = the rejoin watch's
 // set-up and hand-back stubs, empty without it; `mark` is passed either way)
-#define WA_ASM_RUN_LAZY(STEP, W, REJINIT, REJEXITS)                                                                 \
+#define WA_ASM_RUN_LAZY(STEP, W, REJINIT, REJEXITS, T)                                                                 \
     asm volatile(                                                                                                 \
-        WA_ASM_PROLOGUE                                                                                           \
+        WA_ASM_PROLOGUE_##T                                                                                       \
         "ds_read_b32 v99, %[lc] offset:" WA_LC_OFF_STAMP "\n"        /* stamp offset of this lane's neighbour */                 \
         "ds_read_b32 v94, %[lc] offset:" WA_LC_OFF_PARAM "\n"        /* lanes 0..2: clean value, evap_now + 1, rho; 3, 4: version, hold-off */ \
         "v_mov_b32 v96, %[sio]\n"                                                                                 \
@@ -669,12 +754,12 @@
         "global_load_dword v97, v98, %[stamp]\n"                                                                  \
         WA_ASM_STAMPS_INIT                                                                                        \
         "Lwa_top%=:\n"                                                                                            \
-        STEP("v71", "v72", "v96", "v73", "v74", "v97", "a", W)                                                     \
-        STEP("v73", "v74", "v97", "v71", "v72", "v96", "b", W)                                                     \
-        STEP("v71", "v72", "v96", "v73", "v74", "v97", "c", W)                                                     \
-        STEP("v73", "v74", "v97", "v71", "v72", "v96", "d", W)                                                     \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "a", W, T)                                                     \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "b", W, T)                                                     \
+        STEP("v71", "v72", "v96", "v73", "v74", "v97", "c", W, T)                                                     \
+        STEP("v73", "v74", "v97", "v71", "v72", "v96", "d", W, T)                                                     \
         "s_branch Lwa_top%=\n"                                                                                    \
-        WA_ASM_COLL("a") WA_ASM_COLL("b") WA_ASM_COLL("c") WA_ASM_COLL("d")                                       \
+        WA_ASM_COLL("a", T) WA_ASM_COLL("b", T) WA_ASM_COLL("c", T) WA_ASM_COLL("d", T)                                       \
         WA_ASM_DIRTY("v71", "v72", "a") WA_ASM_DIRTY("v73", "v74", "b") WA_ASM_DIRTY("v71", "v72", "c") WA_ASM_DIRTY("v73", "v74", "d") \
         "Lwa_rare_a%=:\n v_mov_b32 %[sio], v96\n" WA_ASM_RARE_BODY("v71", "v72", "0")                             \
         "Lwa_rare_b%=:\n v_mov_b32 %[sio], v97\n" WA_ASM_RARE_BODY("v73", "v74", "1")                             \
@@ -792,7 +877,7 @@ __device__ __forceinline__ void wa_glibc_seek(const int32_t *snap, int32_t k, in
 // re-requests the records: ~1 us per 64 steps).  A dead end is handed to the caller's generic loop undecided: the reference only calls
 // rand() when a candidate exists (:162-166), and the loop's single exit does not say which of the two dead ends it met.
 // DIRECT: no look-ahead (W = DIRECT above): every lane block requests the record of `cur` itself, the active block is always block 0
-template <int VARIANT, bool WARM = true, bool REFDRAW = false, bool DIRECT = false>
+template <int VARIANT, bool WARM = true, bool REFDRAW = false, bool DIRECT = false, bool T16 = false>
 __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__restrict__ pher, const float *__restrict__ heur,
                                                  const uint32_t *__restrict__ stamp, float clean_info, uint32_t evap_now,
                                                  int32_t *path, int32_t *tab, int hash_log2, int32_t nx, int32_t nxy,
@@ -801,8 +886,14 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
                                                  int32_t *flags_out, const int32_t *prefix_words, unsigned long long *dbg,
                                                  const uint32_t *__restrict__ mark = nullptr, uint32_t ver = 0, int32_t hold_off = 0,
                                                  const uint32_t *cut_list = nullptr, int32_t cut_n = 0x7fffffff,
-                                                 int32_t *rng_rs = nullptr, int32_t *rng_f = nullptr, int32_t *rng_b = nullptr)
+                                                 int32_t *rng_rs = nullptr, int32_t *rng_f = nullptr, int32_t *rng_b = nullptr,
+                                                 uint32_t t16_kmul = 0)
 {
+    // T16: the table holds 16-bit entries (WaTabu in acs_walk.hpp; only the loops without touch loads know them); t16_kmul = their multiplier.
+    // A compile-time choice: two inline statements merged under a run-time branch lose their scalar outputs to vector registers.
+    static_assert(!T16 || (!WARM && !DIRECT && !REFDRAW), "16-bit tabu entries: the loops without touch loads only");
+    t16_kmul = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)t16_kmul);
+    constexpr bool t16 = T16;
     if (!cut_list) cut_n = 0x7fffffff;   // straggler check off (see WA_ASM_CUT); st.reason = 5 when the ant left through it
     cut_n = __builtin_amdgcn_readfirstlane(cut_n);   // (an SGPR operand of the loop: neither a literal nor a lane value)
     constexpr bool LAZY = VARIANT == 1 || VARIANT == 3, REJOIN = VARIANT == 2 || VARIANT == 3;
@@ -816,6 +907,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const int32_t limit_full = path_cap < spill_at + 1 ? path_cap : spill_at + 1;
     int32_t limit = limit_full;   // (REFDRAW: the end of the current block, see below)
     const int32_t table = 1 << hash_log2;
+    const int32_t tab_dw = t16 ? table / 2 : table;   // dwords the table takes: what lies behind it (sentinel, dummy slots, columns) starts there
     // field bases moved back by the guard band: every offset the loop forms is then non-negative
     const char *pher_b = reinterpret_cast<const char *>(pher) - guard_bytes;
     const char *heur_b = reinterpret_cast<const char *>(heur) - guard_bytes;
@@ -824,19 +916,20 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     const int32_t c0 = lane;
     const int32_t c1 = dj * 24 + k2 * 4 + guard_bytes;                          // record of neighbour j, edge k2
     const int32_t c2 = (dj + dk) * 24 + 4 + guard_bytes;                        // bytes 4..19 of the record two hops away
-    const int32_t c3 = (int32_t)((uint32_t)dk * 2654435761u);                   // hash of (cur + dk) = cur*K + dk*K
+    const int32_t c3 = (int32_t)((uint32_t)dk * (t16 ? t16_kmul : 2654435761u));  // hash of (cur + dk) = cur*K + dk*K
     const int32_t c4 = dk;
     const int32_t c5 = (int32_t)((uint32_t)dk + ((uint32_t)k2 << WA_K_SHIFT));  // cur + this = path word of the move
-    const int32_t c6 = (table + WA_WALK_LDS_PAD + lane) * 4;                    // this lane's dummy slot
-    if (LAZY || REJOIN) {   // two columns of 64 dwords behind the dummy slots
-        int32_t *lc = tab + table + WA_WALK_LDS_PAD + 64;
+    const int32_t c6 = (tab_dw + WA_WALK_LDS_PAD + lane) * 4;                   // this lane's dummy slot
+    if (LAZY || REJOIN || t16) {   // two columns of 64 dwords behind the dummy slots
+        int32_t *lc = tab + tab_dw + WA_WALK_LDS_PAD + 64;
         if (LAZY) lc[WA_LC_COL_STAMP * 64 + lane] = dj * 4 + stamp_guard_bytes;   // stamp of neighbour j
         // lanes 0..2: clean value, evap_now + 1, rho (lazy field); lanes 3, 4: best-path version, hold-off (rejoin watch)
+        // ... lanes 5, 6: the multiplier and the second shift of the 16-bit entries
         lc[WA_LC_COL_PARAM * 64 + lane] = lane == 0 ? __float_as_int(clean_info) : lane == 1 ? (int32_t)(evap_now + 1u) : lane == 2 ? __float_as_int(R.rho)
-                                          : lane == 3 ? (int32_t)ver : hold_off;
+                                          : lane == 3 ? (int32_t)ver : lane == 5 ? (int32_t)t16_kmul : lane == 6 ? 16 - hash_log2 : hold_off;
     }
-    const int32_t lcaddr = (table + WA_WALK_LDS_PAD + 64 + lane) * 4;
-    int32_t cur = st.cur, len = st.len, g8 = 0;
+    const int32_t lcaddr = (tab_dw + WA_WALK_LDS_PAD + 64 + lane) * 4;
+    int32_t cur = __builtin_amdgcn_readfirstlane(st.cur), len = __builtin_amdgcn_readfirstlane(st.len), g8 = 0;   // (wave-uniform; the loop takes them as scalars)
     int32_t pbuf = st.cur;
     if (REJOIN && st.pbuf_valid) pbuf = st.pbuf;
     else if (prefix_words)   // (through L2: the words may have been stored by this very wavefront a moment ago)
@@ -865,7 +958,7 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         h = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(heur) + boff);
     }
     uint32_t pd = LAZY ? stamp[cur] : 1u;
-    const int32_t hshift = 32 - hash_log2, hm4 = (table - 1) * 4;
+    const int32_t hshift = t16 ? 31 - hash_log2 : 32 - hash_log2, hm4 = t16 ? (table - 1) * 2 : (table - 1) * 4;   // (16-bit entries: the slot's BYTE address = (t >> hshift) & hm4)
     int32_t em = 63;   // the loop raises an event whenever (node count & em) == 0: a completed block -- or, with 15, a straggler check inside one
     int exit_code;   // 1 dead end, 2 arrived, 3 leave the fast loop (table load / path capacity): the caller's generic loop goes on, 5 straggler
     for (;;) {
@@ -873,15 +966,19 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
         if ((len | 63) + 1 > limit_full) { exit_code = 3; break; }
         if (REFDRAW) limit = (len | 63) + 1;
         int32_t code;
+        // (T16: 16-bit tabu entries -- saturated launches only, i.e. the loops without touch loads)
         if (REJOIN && !LAZY) {
-            if (DIRECT) { WA_ASM_RUN_REJ(DIRECT) } else if (WARM) { WA_ASM_RUN_REJ(SELF) } else { WA_ASM_RUN_REJ(NONE) }
+            if (DIRECT) { WA_ASM_RUN_REJ(DIRECT, T32) } else if (WARM) { WA_ASM_RUN_REJ(SELF, T32) } else if constexpr (T16) { WA_ASM_RUN_REJ(NONE, T16) } else { WA_ASM_RUN_REJ(NONE, T32) }
         } else if (!LAZY) {
-            if (DIRECT) { WA_ASM_RUN_DENSE(DIRECT) } else if (WARM) { WA_ASM_RUN_DENSE(SELF) } else { WA_ASM_RUN_DENSE(NONE) }
+            if (DIRECT) { WA_ASM_RUN_DENSE(DIRECT, T32) } else if (WARM) { WA_ASM_RUN_DENSE(SELF, T32) } else if constexpr (T16) { WA_ASM_RUN_DENSE(NONE, T16) } else { WA_ASM_RUN_DENSE(NONE, T32) }
         } else if (REJOIN) {
-            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, DIRECT, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
-            else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, SELF, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS) }
+            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, DIRECT, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS, T32) }
+            else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, SELF, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS, T32) }
+            else if constexpr (T16) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS, T16) }
+            else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY_REJ, NONE, WA_ASM_REJ_INIT, WA_ASM_REJ_EXITS, T32) }
         } else {
-            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, DIRECT, "", "") } else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, SELF, "", "") } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "") }
+            if (DIRECT) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, DIRECT, "", "", T32) } else if (WARM) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, SELF, "", "", T32) }
+            else if constexpr (T16) { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "", T16) } else { WA_ASM_RUN_LAZY(WA_ASM_STEP_LAZY, NONE, "", "", T32) }
         }
 #if defined(WA_ASM_STAMPS)
         if (dbg && lane == 0) {
@@ -926,7 +1023,13 @@ __device__ __forceinline__ void wa_walk_fast_asm(const WaRun &R, const float *__
     if (dbg && lane == 0) atomicAdd(&dbg[8], (unsigned long long)(len - st.len));
 #endif
     if (exit_code == 5) st.reason = 5;
-    st.done = exit_code != 3 && exit_code != 4 && exit_code != 5;
+    if (exit_code == 6) {   // (16-bit entries) a probe chain ran past displacement 13: the loop cannot decide that lane
+        // (left from inside a step: a block completed by the step before is still in pbuf -- its store belongs to the event this step had pending)
+        if ((len & 63) == 0 && len != st.len) path[(len - 64) + lane] = pbuf;
+        if (cur == end) exit_code = 2;   // ... and so is an arrival: the step that was being looked at is the one that would have found it (:182-186)
+        else st.reason = 6;              // (the caller takes this one step with exact lookups -- fourteen slots decide -- and comes back)
+    }
+    st.done = exit_code != 3 && exit_code != 4 && exit_code != 5 && exit_code != 6;
     // :78, one add of `precision` per step taken (table).  A walk handed back by the rejoin watch does not need it yet: the
     // load would sit on the path of every re-entry
     float L = exit_code == 1 ? INFINITY : (exit_code == 4 || exit_code == 5) ? 0.f : ltab[len - 1];

@@ -110,6 +110,8 @@ struct wa_acs {
     std::vector<int> slot_buf;           // which of the two buffers holds slot q's current field (inactive slots do not follow the flips)
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     int walk_warm;         // touch loads in the hand-scheduled loop: -1 by launch size (wa_acs_run), 0 / 1 forced (WA_WALK_WARM)
+    int32_t last_walk[4];  // wa_acs_walk_info
+    int tab16_env, id_bits; // WA_TAB16 (-1 by rule, 0 never, 1 wherever possible); bits of the grid's voxel ids
     int lds_pad;           // WA_WALK_LDS_PAD: experiment knob, extra dynamic LDS per walk block (occupancy at a constant table)
     int walk_direct;       // the loop WITHOUT look-ahead for saturated launches: -1 by rule (walk_direct_rule), 0 / 1 forced (WA_WALK_DIRECT)
     int walk_flags;        // k_walk_dev's switches: hand-scheduled loop, re-entry onto the replay track (WA_REENTRY=0: off), see acs_create
