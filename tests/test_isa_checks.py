@@ -32,6 +32,8 @@ def test_walk26_loop_keeps_its_loads_and_registers_to_itself(device_asm):
     problems, info = chk.check(device_asm)
     assert not problems, problems
     assert info["touch_loads"] >= 4 and info["deferred_pairs"] >= 1 and info["highest_own_vgpr"] < 200
+    lazy = [chk.check_kernel(device_asm.split("\n"), i)[1] for i, l in enumerate(device_asm.split("\n")) if l.startswith("_Z12k_walk_dev26ILb1E")]
+    assert lazy and lazy[0]["deferred_singles"] >= 1          # the stamp load of the lazily evaporated field
 
 
 def test_walk26_checker_sees_what_it_is_there_for(device_asm):
@@ -55,6 +57,15 @@ def _doctored(chk, lines, k0):
     t = next(i for i, l in enumerate(body) if "global_load_dword v250" in l)
     stray = lines[:k0] + body[:t] + ["\tv_mov_b32_e32 v3, v251"] + body[t:] + lines[k1:]
     assert any("outside the touch loads" in p for p in chk.check("\n".join(stray))[0])
+    # a SINGLE load with a deferred wait (the lazily evaporated field's stamp) is followed like the pairs -- a copy of its register right
+    # behind the load, before any wait, must be seen
+    _, info = chk.check_kernel(lines, k0)
+    for site in info["single_sites"]:
+        reg = sorted(chk.vregs(site.split(",")[0]))[0]
+        at = [i for i, l in enumerate(body) if l.split(";")[0].strip() == site]
+        assert at
+        copied = lines[:k0] + body[:at[0] + 1] + ["\tv_mov_b32_e32 v3, v%d" % reg] + body[at[0] + 1:] + lines[k1:]
+        assert any("touched before their wait" in p for p in chk.check("\n".join(copied))[0]), site
 
 
 DIAG_BUILDS = [["-DWA_STAMPS"], ["-DWA_ANT_TIME"], ["-DWA_STRAG_TIME"], ["-DWA_ASM_STAMPS"], ["-DWA_ASM_SPAN_A=2", "-DWA_ASM_SPAN_B=5"],

@@ -4,8 +4,9 @@
 touch loads land in v250..v253, which only the statement's clobber list names.  Checked on the assembled kernel:
 
   1. v250..v253 appear in no instruction of the kernel other than the touch loads themselves;
-  2. from every record-load pair that is not waited for on the spot, along EVERY control-flow path, no instruction reads or writes the
-     two destination registers before an `s_waitcnt` with vmcnt <= 4 has been passed (no copy, no phi move, no spill in between);
+  2. from EVERY load that is not waited for on the spot -- the record-load pairs, and single loads such as the lazily evaporated field's stamp --,
+     along EVERY control-flow path, no instruction reads or writes its destination registers before an `s_waitcnt vmcnt(N)` has been passed with
+     N <= the vector-memory instructions issued behind it on that path (no copy, no phi move, no spill, no younger load in between);
   3. apart from the clobbered v250..v253 the kernel's own registers stay far below them.
 
     python tools/check_walk26_isa.py [file.s]        (no GPU needed; without a file the library's device code is assembled with hipcc -S)
@@ -80,42 +81,59 @@ def check_kernel(lines, start):
                 problems.append("v250..v253 used outside the touch loads: [%d] %s" % (i, t))
     if touch_sites == 0 or touch_sites % 4:
         problems.append("expected groups of four touch loads, found %d" % touch_sites)
-    # 2. issue ... wait
-    def waits_vm(t, limit):
+    # 2. issue ... wait.  EVERY load of the kernel whose result is not waited for on the spot -- pairs, and singles such as the lazily evaporated
+    # field's stamp load -- is followed along every control-flow path: vector memory returns in order, so its registers are
+    # good once an s_waitcnt vmcnt(N) has been passed with N <= the vector-memory instructions issued behind it on that path; until then no
+    # instruction may read or write them (no copy, no phi move, no spill, no younger load into the same register)
+    def waits_vm(t):
         m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", t)
-        return bool(m) and int(m.group(1)) <= limit
-    pairs = 0
-    for i in range(len(ins) - 1):
-        a, b = ins[i], ins[i + 1]
-        if not (a.startswith("global_load_dword v") and b.startswith("global_load_dword v")):
+        return int(m.group(1)) if m else None
+    def is_vmem(t):
+        return t.startswith(("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load", "flat_store", "flat_atomic", "scratch_"))
+    pairs = singles = 0
+    single_sites = []
+    for i in range(len(ins)):
+        if not ins[i].startswith("global_load_dword") or vregs(ins[i].split(",")[0]) & TOUCH:
             continue
-        ra, rb = vregs(a.split(",")[0]), vregs(b.split(",")[0])
-        if (ra | rb) & TOUCH or (i > 0 and ins[i - 1].startswith("global_load_dword v25")):
-            continue
-        if i + 2 < len(ins) and waits_vm(ins[i + 2], 0):
-            continue                                    # waited for on the spot (the loads in front of the loop)
-        regs = ra | rb
-        pairs += 1
-        seen, todo = set(), [i + 2]
-        while todo:
-            k = todo.pop()
-            while k < len(ins) and k not in seen:
-                seen.add(k)
+        regs = vregs(ins[i].split(",")[0])
+        # (a load is followed on its own: the loads behind it in the same run are among its `younger` ones -- the compiler's partial waits on a long
+        #  run, vmcnt(20) in front of the use of the run's first results, pass the same rule as the loop's exact vmcnt(4))
+        deferred_here = False
+        seen, todo = set(), [(i + 1, 0)]
+        bad = None
+        while todo and bad is None:
+            k, younger = todo.pop()
+            while k < len(ins) and (k, min(younger, 64)) not in seen:
+                seen.add((k, min(younger, 64)))
                 t = ins[k]
-                if waits_vm(t, 4):
+                n = waits_vm(t)
+                if n is not None and n <= younger:
+                    if n > 0:
+                        deferred_here = True
                     break
                 op = t.split(None, 1)
                 if len(op) > 1 and vregs(op[1]) & regs:
-                    problems.append("records loaded at [%d] (v%s) touched before their wait: [%d] %s" % (i, sorted(regs), k, t))
+                    bad = "records loaded at [%d] (v%s) touched before their wait: [%d] %s" % (i, sorted(regs), k, t)
                     break
+                if is_vmem(t):
+                    younger += 1
                 if t.startswith("s_endpgm"):
                     break
                 m = re.match(r"s_c?branch\w*\s+(\S+)", t)
                 if m and m.group(1) in labels:
-                    todo.append(labels[m.group(1)])
+                    todo.append((labels[m.group(1)], younger))
                     if t.startswith("s_branch"):
                         break
                 k += 1
+        if bad:
+            problems.append(bad)
+        elif deferred_here:
+            # (the loop's own: a deferred wait of exactly four -- the touch loads -- behind a record pair, or behind the pair + the lazy field's stamp)
+            if i + 1 < len(ins) and ins[i + 1].startswith("global_load_dword") and not (vregs(ins[i + 1].split(",")[0]) & TOUCH):
+                pairs += 1
+            else:
+                singles += 1
+                single_sites.append(ins[i])
     if pairs == 0:
         problems.append("no record-load pair with a deferred wait found: has the loop changed?")
     # 3. register budget
@@ -127,7 +145,7 @@ def check_kernel(lines, start):
     top = max(own) if own else -1
     if top >= 200:
         problems.append("the kernel's own VGPRs reach v%d: too close to the hard-coded touch registers" % top)
-    return problems, dict(instructions=len(ins), deferred_pairs=pairs, touch_loads=touch_sites, highest_own_vgpr=top)
+    return problems, dict(instructions=len(ins), deferred_pairs=pairs, deferred_singles=singles, single_sites=single_sites, touch_loads=touch_sites, highest_own_vgpr=top)
 
 
 def main():
@@ -139,7 +157,7 @@ def main():
             print("  " + p)
         return 1
     print("k_walk_dev26 ISA check ok (%(kernels)d instantiation(s)): %(instructions)d instructions, %(deferred_pairs)d record-load pairs with a deferred wait, "
-          "%(touch_loads)d touch loads in v250..v253, highest VGPR of its own v%(highest_own_vgpr)d" % info)
+          "%(deferred_singles)d single loads with one, %(touch_loads)d touch loads in v250..v253, highest VGPR of its own v%(highest_own_vgpr)d" % info)
     return 0
 
 
