@@ -1,3 +1,5 @@
+"""Round 6: 16-bit tabu entries on the 256^3 pair-planning batch (120 pairs x 24 ants x 150 generations): walk geometry, time, walks spilled to the
+bitmap and how many of them because a 16-bit entry found no slot within 14 (wa_acs_debug_counters [13], [14]; knobs build).  profiles/r06/tab16.txt"""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'examples')
 import numpy as np

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extract the hand-scheduled walk loop as assembled (hipcc -S, device only) and count its instructions.
 
-    python tools/walk_isa.py [out.txt]        (default profiles/r03/walk_loop_isa.txt; no GPU needed)
+    python tools/walk_isa.py [out.txt]        (default profiles/r06/walk_loop_isa.txt; no GPU needed)
 
 The first line of the output is machine-readable -- bench.py derives `walk_step.instructions_per_step` from it
 instead of carrying a number in its source:   # instructions_per_step: N  (4 steps per trip, M instructions per trip)"""
@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from welding_robot_amd import build  # noqa: E402
 
-KERNEL = "_Z10k_walk_devILb1ELb0ELb1ELb0ELb0EEv8WaAcsDev5WaRuniii"   # k_walk_dev<alpha 1, dense, touch loads, no rejoin watch, look-ahead>
+KERNEL = "_Z10k_walk_devILb1ELb0ELb1ELb0ELb0ELb0EEv8WaAcsDev5WaRuniii"   # k_walk_dev<alpha 1, dense, touch loads, no rejoin watch, look-ahead>
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03", "walk_loop_isa.txt")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06", "walk_loop_isa.txt")
     asm = "/tmp/weldacs_walk_%d.s" % os.getpid()
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
     subprocess.check_call([build.hipcc()] + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "weldacs.hip"), "-o", asm],
