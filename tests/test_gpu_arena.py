@@ -87,7 +87,8 @@ def test_solvers_of_other_shapes_feed_a_c5_sized_solver_on_poisoned_memory():
     kept_big = ctx.cached_bytes()
     assert kept_big > 150 * GiB
     free1, _ = ctx.memory_info()
-    assert abs(free1 - free0) < 2 * GiB        # kept memory counts as free
+    if not os.environ.get("PYTEST_XDIST_WORKER"):   # (the device's free memory is everybody's: other xdist workers allocate meanwhile)
+        assert abs(free1 - free0) < 2 * GiB        # kept memory counts as free
     # the same solver again: built entirely from kept chunks
     before = ctx.cache_stats()
     s, t_second = create_timed(ctx, g256, slots, 24, True)

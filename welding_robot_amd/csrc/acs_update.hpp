@@ -122,7 +122,9 @@ __device__ inline void wa_std_sort(WaRec *v, int32_t n)
 // ranking (:273-275), per-rank deposit coefficient, trace, next generation's parameters.
 // The (L, ant) sort keys are staged in LDS (up to WA_RANK_LDS ants) so the counting rank reads
 // broadcast LDS words instead of a dependent chain of global loads.
+#ifndef WA_RANK_LDS
 #define WA_RANK_LDS 2048
+#endif
 template <int NB>
 __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
 {
