@@ -65,12 +65,14 @@ def main():
     s.reset_pheromone(1.0)
     ctx.sync()
     t0 = time.perf_counter()
-    s.solve(p, a, b, streams=list(range(slots)))
-    ctx.sync()
+    s.begin(p, a, b, streams=list(range(slots)))
+    s.run(gens)
+    t_enq = time.perf_counter() - t0
+    s.sync()
     t = time.perf_counter() - t0
     steps = sum(int(s.trace(q)["steps"].sum()) for q in range(slots))
-    print("order %r: %d^3, %d slots x 24 ants, %d generations (the SECOND of two identical batches): %.2f ms, %d ant steps = %.3f G steps/s; walk geometry %s"
-          % (order, n, slots, gens, t * 1e3, steps, steps / t / 1e9, s.walk_info()), flush=True)
+    print("order %r: %d^3, %d slots x 24 ants, %d generations (the SECOND of two identical batches): %.2f ms (the host had enqueued it after %.2f ms), %d ant steps = %.3f G steps/s; walk geometry %s"
+          % (order, n, slots, gens, t * 1e3, t_enq * 1e3, steps, steps / t / 1e9, s.walk_info()), flush=True)
     print("   (both batches run the same %d steps: counter totals of the whole process / 2 = one batch)" % steps)
 
 

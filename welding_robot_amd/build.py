@@ -17,6 +17,9 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libweldacs.so")
 # the same library with the forced-hand-back knobs of tests/test_gpu_reentry.py compiled in (-DWA_TEST_KNOBS); never the product
 KNOBS_LIB_PATH = os.path.join(LIB_DIR, "libweldacs_knobs.so")
+# the knobs library with ONE regression put back on purpose (-DWA_BEST_READ_LATE: k_evap_rank_mark's publishing block reads the old best behind its barriers):
+# the negative half of tests/test_gpu_late_waves.py -- the knob must be able to open the window it guards.  Never the product
+LATE_READ_LIB_PATH = os.path.join(LIB_DIR, "libweldacs_knobs_late_read.so")
 SOURCES = ["weldacs.hip"]
 DEPS = ["wa_device.h", "acs_kernels.hpp", "acs_dev.hpp", "acs_walk.hpp", "acs_update.hpp", "acs_nb26.hpp", "walk_loop_gfx950.hpp", "grid_kernels.hpp", "gtsp_kernels.hpp", "traj_kernels.hpp",
         "stl_text.hpp", "host_grid.inc", "host_acs.inc", "host_gtsp.inc", "host_traj.inc", "host_comm.inc"]
@@ -93,11 +96,19 @@ def build_knobs(force=False, verbose=False):
     return build(force=True, verbose=verbose, extra=["-DWA_TEST_KNOBS"], out=KNOBS_LIB_PATH)
 
 
+def build_late_read(force=False, verbose=False):
+    """lib/libweldacs_knobs_late_read.so (see LATE_READ_LIB_PATH)"""
+    if not force and not needs_build(LATE_READ_LIB_PATH):
+        return LATE_READ_LIB_PATH
+    return build(force=True, verbose=verbose, extra=["-DWA_TEST_KNOBS", "-DWA_BEST_READ_LATE"], out=LATE_READ_LIB_PATH)
+
+
 if __name__ == "__main__":
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
     if "--knobs" in sys.argv:
         print(build_knobs(force="--force" in sys.argv, verbose=True))
+        print(build_late_read(force="--force" in sys.argv, verbose=True))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, out=outs[0] if outs else None,
                 extra=defs + (["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])))

@@ -367,6 +367,14 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     __shared__ int32_t s_ndep, s_fin;
     __shared__ unsigned long long s_steps;
     if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
+    // Block 0 compares the iteration's best with the global best and then REPLACES it (its thread 0, behind the second barrier below).  Every thread
+    // takes its copy of the old best HERE, in front of the barriers: read behind them, a wavefront that is scheduled late found the value thread 0
+    // had just published, took the new best for no improvement and skipped its quarter of the path copy -- 64 stale words in bestpath[], once in
+    // ~3 000 searches of a saturated batch when the launch keeps eight blocks per CU resident (round 6: tools/state_hash.py, profiles/r06/best_copy_race.txt)
+    float bestL = INFINITY;
+    uint32_t ver = 0;
+    int32_t blen = 0;
+    if (mb == 0) { bestL = ctl->bestL; ver = ctl->best_ver; blen = ctl->best_len; }
     // This block is a chain of dependent global loads beside a sweep that saturates the memory system (every level costs 2-3 us there):
     // the ants' results are requested for ALL max_colony ants before the control block says how many there are (inside the allocation;
     // entries beyond the colony are never looked at), and every ant's length goes to LDS with its key, so that the ranked ant's length is
@@ -415,9 +423,16 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         float iterL = INFINITY;
         int32_t iterAnt = -1;
         if (colony > 0) { iterAnt = s_perm[0]; iterL = __uint_as_float((uint32_t)(s_keys[iterAnt] >> 32)); }  // rank 1 = first ant with the minimal L
-        float bestL = ctl->bestL;
-        uint32_t ver = ctl->best_ver;
-        int32_t blen = ctl->best_len;
+#ifdef WA_TEST_KNOBS
+        // test knob (tests/test_gpu_late_waves.py): wavefronts 1..3 of the publishing block fall ~20 us behind wavefront 0 right here
+        if ((sweep_nt & 0x400) && (tid >> 6) != 0) { for (int z = 0; z < 8; z++) __builtin_amdgcn_s_sleep(127); asm volatile("" ::: "memory"); }   // (8 x 127 x 64 clocks; no memory access moves across)
+#endif
+#ifdef WA_BEST_READ_LATE   // (diagnostic build: the reads where they were before the fix, for the negative half of tests/test_gpu_late_waves.py)
+        // (read past the CU's vector cache, where a quiet GPU would still hold the old line: in a saturated launch that line has long been evicted)
+        bestL = __hip_atomic_load(&ctl->bestL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ver = __hip_atomic_load(&ctl->best_ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        blen = __hip_atomic_load(&ctl->best_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         bool changed = false;
         if (iterAnt >= 0 && iterL < bestL) {
             blen = s_len[iterAnt];
@@ -707,3 +722,86 @@ __global__ __launch_bounds__(256) void k_lazy_materialise(WaAcsDev D, WaRun R, i
     const uint32_t stv = D.stamp[(int64_t)slot * D.d.n + v];
     out[e] = stv != 0 ? wa_catch_up(fabsf(st0), evap_now + 1u - stv, R.rho) : (fabsf(st0) == 0.f ? 0.f : clean);
 }
+
+#ifdef WA_STATE_HASH
+// ------------------------------------------------------------------ diagnostic build (-DWA_STATE_HASH, tools/state_hash.py): an order-free digest
+// of everything a search's next kernel depends on, taken behind every launch of the generation loop.  Two runs of the same batch must produce the
+// same digests whatever the timing; the first (generation, launch, slot, part) that differs names the kernel whose output depends on scheduling.
+// Lazily evaporated fields are digested as the VALUES they stand for (pending evaporations applied): which records the background pass
+// refreshed in which generation depends on the order the voxels joined the dirty list, the values do not.
+// parts: [0] field values, [1] set of dirty voxels, [2] rank masks, [3] the ants' results and paths, [4] best path, [5] control block + dirty count,
+//        [6] prefix-tabu bits of the best path, [7] replay table (both rebuilt by the apply + table launch: stale behind the launch in front of it)
+__device__ __forceinline__ unsigned long long wa_h2(unsigned long long a, unsigned long long b)
+{
+    return wa_mix64(a * 0x9E3779B97F4A7C15ULL + wa_mix64(b + 0x632BE59BD9B4E019ULL));
+}
+__global__ __launch_bounds__(256) void k_state_hash(WaAcsDev D, WaRun R, unsigned long long *out, int32_t phase)
+{
+    const int32_t slot = blockIdx.y, tid = threadIdx.x;
+    const WaSlotCtl *c = &D.ctl[slot];
+    const int32_t g = c->gen;
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float *ph = D.pher + (int64_t)slot * D.pher_stride;
+    const uint32_t *stamp = D.stamp ? D.stamp + (int64_t)slot * D.d.n : nullptr;
+    const WaMaskRef mask = wa_mask_of(D, slot);
+    const float clean = c->clean[g & 1];
+    const uint32_t evap_now = c->evap_base + (uint32_t)g;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + tid; v < D.d.n; v += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t stv = stamp ? stamp[v] : 1u;
+        for (int k = 0; k < 6; k++) {
+            const int64_t e = v * 6 + k;
+            const float st0 = ph[e];
+            float val = fabsf(st0);
+            if (stamp) val = stv != 0 ? wa_catch_up(val, evap_now + 1u - stv, R.rho) : (val == 0.f ? 0.f : clean);
+            h[0] += wa_h2((unsigned long long)e, (unsigned long long)(__float_as_uint(val) | (__float_as_uint(st0) & 0x80000000u)));
+            const unsigned long long m = wa_mask_get(mask, e);
+            if (m) h[2] += wa_h2((unsigned long long)e, m);
+        }
+        if (stamp && stv != 0) h[1] += wa_h2((unsigned long long)v, 1ULL);
+    }
+    if (blockIdx.x == 0) {
+        for (int32_t a = 0; a < D.max_colony; a++) {
+            const float La = D.antL[(int64_t)slot * D.max_colony + a];
+            const int32_t na = D.antLen[(int64_t)slot * D.max_colony + a];
+            if (tid == 0) h[3] += wa_h2((unsigned long long)a, ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)na);
+            const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
+            if (a < c->colony[(g + 1) & 1] || a < c->colony[g & 1])
+                for (int32_t j = tid; j < na && j < D.path_cap; j += blockDim.x) h[3] += wa_h2((unsigned long long)a * D.path_cap + j, (unsigned long long)(uint32_t)path[j]);
+        }
+    }
+    if (blockIdx.x == 1 && c->bestL != INFINITY) {
+        const int32_t blen = c->best_len;
+        for (int32_t i = tid; i < blen; i += blockDim.x) {
+            h[4] += wa_h2((unsigned long long)i, (unsigned long long)(uint32_t)D.bestpath[(int64_t)slot * D.path_cap + i]);
+            h[6] += wa_h2((unsigned long long)i + (1ULL << 32), (unsigned long long)D.besttabu[(int64_t)slot * D.path_cap + i]);
+            if (D.rtab) for (int k = 0; k < 8; k++) h[7] += wa_h2((unsigned long long)i * 8 + k + (2ULL << 32), (unsigned long long)__float_as_uint(D.rtab[((int64_t)slot * D.path_cap + i) * 8 + k]));
+        }
+    }
+    if (blockIdx.x == 2 && tid == 0) {
+        unsigned long long x = 0;
+        // (best_ver, tabu_gen and evap_base carry over from solve to solve; n_dep / dep_* / perm / depA are the previous solve's until the first ranking)
+        x = wa_h2(x, __float_as_uint(c->bestL)); x = wa_h2(x, (uint32_t)c->best_len);
+        x = wa_h2(x, (uint32_t)c->colony[0]); x = wa_h2(x, (uint32_t)c->colony[1]); x = wa_h2(x, __float_as_uint(c->lambda[0])); x = wa_h2(x, __float_as_uint(c->lambda[1]));
+        x = wa_h2(x, __float_as_uint(c->Q[0])); x = wa_h2(x, __float_as_uint(c->Q[1])); x = wa_h2(x, __float_as_uint(c->clean[g & 1])); x = wa_h2(x, (uint32_t)g);
+        if (phase > 0) {
+            x = wa_h2(x, (uint32_t)c->n_dep); x = wa_h2(x, (uint32_t)(c->tabu_gen == g - 1));
+            x = wa_h2(x, __float_as_uint(c->dep_lambda)); x = wa_h2(x, __float_as_uint(c->dep_Q)); x = wa_h2(x, __float_as_uint(c->dep_bestL));
+            for (int32_t o = 0; o < c->n_dep && o < D.max_colony; o++) {
+                x = wa_h2(x, (uint32_t)D.perm[(int64_t)slot * D.max_colony + o]); x = wa_h2(x, __float_as_uint(D.depA[(int64_t)slot * D.max_colony + o]));
+            }
+        }
+        if (D.dcount) { x = wa_h2(x, (uint32_t)D.dcount[slot * 2]); x = wa_h2(x, (uint32_t)D.dcount[slot * 2 + 1]); }
+        h[5] = x;
+    }
+    __shared__ unsigned long long s_h[8];
+    if (tid < 8) s_h[tid] = 0;
+    __syncthreads();
+    for (int i = 0; i < 8; i++) {
+        unsigned long long x = h[i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if ((tid & 63) == 0 && x) atomicAdd(&s_h[i], x);
+    }
+    __syncthreads();
+    if (tid < 8 && s_h[tid]) atomicAdd(&out[(int64_t)slot * 8 + tid], s_h[tid]);
+}
+#endif

@@ -111,6 +111,9 @@ struct wa_acs {
     bool walk_asm;         // hand-scheduled walk loop (default); WA_WALK_ASM=0 keeps the compiler-scheduled one
     int walk_warm;         // touch loads in the hand-scheduled loop: -1 by launch size (wa_acs_run), 0 / 1 forced (WA_WALK_WARM)
     int32_t last_walk[4];  // wa_acs_walk_info
+#ifdef WA_STATE_HASH
+    unsigned long long *d_hashlog = nullptr;   // [WA_HASH_GENS][3][n_slots][8], diagnostic build only (k_state_hash)
+#endif
     int tab16_env, id_bits; // WA_TAB16 (-1 by rule, 0 never, 1 wherever possible); bits of the grid's voxel ids
     int lds_pad;           // WA_WALK_LDS_PAD: experiment knob, extra dynamic LDS per walk block (occupancy at a constant table)
     int walk_direct;       // the loop WITHOUT look-ahead for saturated launches: -1 by rule (walk_direct_rule), 0 / 1 forced (WA_WALK_DIRECT)
