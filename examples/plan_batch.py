@@ -57,7 +57,7 @@ def plan(ctx, grid, point_ids, generations, predict, seed, slots, rank=0, world=
     paths = {}
     plan.last_batch_s = []                             # seconds per batch: solve / reset / read-back (tools/walk_direct_ab.py --batches)
     for b0 in range(0, len(mine), slots):
-        idx = mine[b0:b0 + slots]
+        idx = mine[b0:b0 + slots] if by_length else wd.order_batch(mine[b0:b0 + slots], weights)   # (longest searches first in each half of the slots)
         tb = [time.perf_counter()]
         solver.solve(p, [point_ids[pairs[k][0]] for k in idx], [point_ids[pairs[k][1]] for k in idx], streams=idx)
         tb.append(time.perf_counter())

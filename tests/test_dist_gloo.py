@@ -205,3 +205,22 @@ def test_pairs_are_dealt_longest_first_over_end_point_groups():
     shards, load = wd.deal_pairs(pairs5, w5, 3)
     assert sorted(k for sh in shards for k in sh) == list(range(10)) and max(load) - min(load) <= max(w5)
     assert wd.deal_pairs(pairs5, w5, 3) == (shards, load)
+
+
+def test_a_batch_is_ordered_longest_first_in_each_half_of_its_slots():
+    """order_batch: the slot order of ONE batch -- a permutation of the batch; each half of the slots (one pipelined group of the library) starts with
+    its longest search and descends; the two halves get alternate entries of the sorted list (equal loads to within one search)."""
+    import numpy as np
+    rs = np.random.RandomState(5)
+    for n in (1, 2, 7, 224):
+        idx = list(rs.permutation(5000)[:n])
+        w = {k: int(rs.randint(1, 700)) for k in idx}
+        o = wd.order_batch(idx, w)
+        assert sorted(o) == sorted(idx)
+        h0, h1 = o[:n // 2], o[n // 2:]                              # group 0 = slots [0, n / 2), group 1 = the rest (wa_acs_run)
+        for h in (h0, h1):
+            assert all(w[h[i]] >= w[h[i + 1]] for i in range(len(h) - 1))
+        if n >= 2:
+            assert max(w[k] for k in idx) in (w[h0[0]], w[h1[0]])
+            assert abs(sum(w[k] for k in h0) - sum(w[k] for k in h1)) <= max(w.values())
+        assert wd.order_batch(idx, w) == o                            # deterministic

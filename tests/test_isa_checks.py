@@ -1,7 +1,7 @@
 """CPU-side checks on the compiled device code (hipcc cross-compiles gfx950 without a GPU):
  * tools/check_walk26_isa.py -- what the 26-neighbour fast loop relies on beyond the compiler's promises: inline-issued
    loads waited for by a later statement, hard-coded touch registers;
- * every diagnostic -D build the tools use still compiles (-DWA_STAMPS, -DWA_ANT_TIME, -DWA_STRAG_TIME, -DWA_ASM_STAMPS,
+ * every diagnostic -D build the tools use still compiles (-DWA_STAMPS, -DWA_ANT_TIME, -DWA_STRAG_TIME, -DWA_ASM_STAMPS, -DWA_STATE_HASH,
    -DWA_ASM_SPAN_A/B), so the measurement tools cannot rot silently."""
 import importlib.util
 import os
@@ -69,7 +69,7 @@ def _doctored(chk, lines, k0):
 
 
 DIAG_BUILDS = [["-DWA_STAMPS"], ["-DWA_ANT_TIME"], ["-DWA_STRAG_TIME"], ["-DWA_ASM_STAMPS"], ["-DWA_ASM_SPAN_A=2", "-DWA_ASM_SPAN_B=5"],
-               ["-DWA_ASM_SPAN_A=10", "-DWA_ASM_SPAN_B=10"], ["-DWA_TEST_KNOBS", "-DWA_STAMPS"]]
+               ["-DWA_ASM_SPAN_A=10", "-DWA_ASM_SPAN_B=10"], ["-DWA_TEST_KNOBS", "-DWA_STAMPS"], ["-DWA_STATE_HASH", "-DWA_RANK_LDS=64"]]
 
 
 def test_every_diagnostic_build_compiles(tmp_path):

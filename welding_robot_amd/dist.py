@@ -45,6 +45,16 @@ def deal_pairs(pairs, weights, world):
     return shards, load
 
 
+def order_batch(idx, weights):
+    """The searches of ONE batch in the order their slots should have: the blocks of a walk launch start in slot order and the launch lasts as long as
+    its longest ant, so the longest searches go first (longest-processing-time-first); the library runs the two halves of the slots as two pipelined
+    groups (wa_acs_run: group k = slots [P k / 2, P (k + 1) / 2)), so the sorted list is dealt alternately to the halves.  Measured on BASELINE
+    config C5 (224 searches per batch on 256^3): 45.2 -> 43.4 ms per batch (profiles/r06/c5_walk_counters.txt).  Results do not depend on the order:
+    every search draws from the stream of its global pair index."""
+    srt = sorted(idx, key=lambda k: (-weights[k], k))
+    return srt[1::2] + srt[0::2]
+
+
 _ID_MAGIC = b"WAID1"
 
 

@@ -272,7 +272,18 @@ public:
                 int nb = (int)std::min<size_t>(batch, mine.size() - b0);
                 std::vector<int64_t> s0(nb), e0(nb);
                 std::vector<uint32_t> st(nb);
-                for (int q = 0; q < nb; q++) { size_t k = mine[b0 + q]; s0[q] = ids[pairs[k].first]; e0[q] = ids[pairs[k].second]; st[q] = (uint32_t)k; }
+                // slot order inside the batch: the blocks of a walk launch start in slot order and the launch lasts as long as its longest ant, so
+                // the longest searches go first; the library runs the two halves of the slots as two pipelined groups, so the sorted list is dealt
+                // alternately to the halves (BASELINE config C5: 45.2 -> 43.4 ms per batch).  Results do not depend on the order (stream = pair index)
+                std::vector<size_t> bord(mine.begin() + (std::ptrdiff_t)b0, mine.begin() + (std::ptrdiff_t)b0 + nb);
+                if (rng_mode != WA_RNG_REF) {
+                    std::sort(bord.begin(), bord.end(), [&](size_t a, size_t b) { return wgt[a] != wgt[b] ? wgt[a] > wgt[b] : a < b; });
+                    std::vector<size_t> dealt;
+                    for (size_t q = 1; q < bord.size(); q += 2) dealt.push_back(bord[q]);
+                    for (size_t q = 0; q < bord.size(); q += 2) dealt.push_back(bord[q]);
+                    bord.swap(dealt);
+                }
+                for (int q = 0; q < nb; q++) { size_t k = bord[(size_t)q]; s0[q] = ids[pairs[k].first]; e0[q] = ids[pairs[k].second]; st[q] = (uint32_t)k; }
                 int rc = wa_acs_solve(sv, &p, nb, s0.data(), e0.data(), st.data());  // computeSolution :480
                 if (rc == WA_OK) rc = wa_acs_reset_pheromone(sv, -1, p.pheromone_0);  // reset() :481
                 if (rc == WA_OK) {
@@ -287,7 +298,7 @@ public:
                     std::vector<int8_t> bk((size_t)nb * (size_t)stride);
                     if (rc == WA_OK && stride > 0) rc = wa_acs_result_batch_choices(sv, nb, bc.data(), bl.data(), bi.data(), bk.data(), stride);
                     for (int q = 0; q < nb && rc == WA_OK; q++) {
-                        PairResult &r = res[mine[b0 + q]];
+                        PairResult &r = res[bord[(size_t)q]];
                         const size_t len = (size_t)bl[(size_t)q];
                         r.cost = bc[(size_t)q];
                         r.ids.assign(bi.begin() + (size_t)q * (size_t)stride, bi.begin() + (size_t)q * (size_t)stride + len);
