@@ -139,56 +139,89 @@ __device__ __forceinline__ void wa_edge_offset(int k, int &dx, int &dy, int &dz)
     dz = k == 0 ? -1 : k == 5 ? 1 : 0;
 }
 
-// ------------------------------------------------------------------ pheromone init / reset
+// ------------------------------------------------------------------ per-voxel field writers (pheromone init / reset, heuristic)
+// One thread per VOXEL: its coordinates cost two 32-bit divisions ONCE, what the NB edges share (the vector to the end point and its norm) is computed
+// once, and the NB values of a block's 256 voxels go through LDS so that the block writes 256 x NB contiguous floats.  Until round 6 these were
+// thread-per-EDGE kernels that spent their time on 64-bit index divisions (k_heuristic: 0.52 ms per 256^3 field = 0.78 TB/s, 63 fields = 33 ms of
+// BASELINE config C5's 0.40 s; k_init_pheromone: 1.3 TB/s).  Same arithmetic per value, in the same order: the fields are bit-identical.
+template <int NB>
+__device__ __forceinline__ void wa_write_voxel_block(float *field, int64_t n_vox, const float (&v)[NB], bool live)
+{
+    __shared__ float s_v[256 * NB];
+    const int tid = threadIdx.x;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) s_v[tid * NB + k] = v[k];
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * 256 * NB, end = n_vox * NB;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int64_t t = base + j * 256 + tid;
+        if (t < end) field[t] = s_v[j * 256 + tid];
+    }
+}
+
 // mode 0: initFromGridMap (out-of-bounds edges 0), mode 1: reset() (every edge pheromone_0).
-// The sign bit is set on edges whose neighbour is out of bounds or occupied.  Thread per (voxel, edge): coalesced 4-byte stores
-// over the [N][NB] field, one definition for both neighbourhoods.
+// The sign bit is set on edges whose neighbour is out of bounds or occupied.  grid = (ceil(N / 256), slots), one definition for both neighbourhoods.
 template <int NB>
 __global__ __launch_bounds__(256) void k_init_pheromone(WaAcsDev D, int32_t slot0, float p0, int32_t mode)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= D.d.n * NB) return;
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const bool live = (int64_t)id < D.d.n;
     const int32_t slot = slot0 + blockIdx.y;
-    const int64_t id = t / NB;
-    const int k = (int)(t - id * NB);
-    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    int dx, dy, dz;
-    wa_edge_offset<NB>(k, dx, dy, dz);
-    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
-    const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
-    const bool adm = inb && D.occ[id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
-    const float v = (inb || mode == 1) ? p0 : 0.f;
-    D.pher[(int64_t)slot * D.pher_stride + t] = adm ? v : -v;
+    float v[NB];
+    if (live) {
+        const uint32_t nx = (uint32_t)D.d.nx, ny = (uint32_t)D.d.ny, row = id / nx;
+        const int32_t x = (int32_t)(id - row * nx), z = (int32_t)(row / ny), y = (int32_t)(row - (uint32_t)z * ny);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            int dx, dy, dz;
+            wa_edge_offset<NB>(k, dx, dy, dz);
+            const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+            const bool inb = X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz;
+            const bool adm = inb && D.occ[(int64_t)id + dz * D.d.nxy + dy * D.d.nx + dx] != 0;
+            const float val = (inb || mode == 1) ? p0 : 0.f;
+            v[k] = adm ? val : -val;
+        }
+    }
+    wa_write_voxel_block<NB>(D.pher + (int64_t)slot * D.pher_stride, D.d.n, v, live);
 }
 
 // ------------------------------------------------------------------ heuristic field
 // (1 + beta*cos) of :151-154 is a function of the voxel, the edge and the END point only: the fields live in a pool,
 // wa_acs_begin computes one per distinct end point of its batch that the pool does not hold yet (`fields` / `ends` = pool
-// index and end point of each field to compute) and every search reads the field ctl.heur_slot names
+// index and end point of each field to compute) and every search reads the field ctl.heur_slot names.  grid = (ceil(N / 256), fields)
 template <int NB>
 __global__ __launch_bounds__(256) void k_heuristic(WaAcsDev D, float beta, const int32_t *fields, const int32_t *ends)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= D.d.n * NB) return;
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const bool live = (int64_t)id < D.d.n;
     const int32_t slot = fields[blockIdx.y];
-    const int64_t id = t / NB;
-    const int k = (int)(t - id * NB);
     const int32_t end = ends[blockIdx.y];
-    const int32_t x = (int32_t)(id % D.d.nx), y = (int32_t)((id / D.d.nx) % D.d.ny), z = (int32_t)(id / D.d.nxy);
-    const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
-    int dx, dy, dz;
-    wa_edge_offset<NB>(k, dx, dy, dz);
-    const int32_t X = x + dx, Y = y + dy, Z = z + dz;
-    float out = 0.f;
-    if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+    float v[NB];
+    if (live) {
+        const uint32_t nx = (uint32_t)D.d.nx, ny = (uint32_t)D.d.ny, row = id / nx;
+        const int32_t x = (int32_t)(id - row * nx), z = (int32_t)(row / ny), y = (int32_t)(row - (uint32_t)z * ny);
+        const int32_t ex = end % D.d.nx, ey = (end / D.d.nx) % D.d.ny, ez = end / D.d.nxy;
         const float ax = D.cx[ex] - D.cx[x], ay = D.cy[ey] - D.cy[y], az = D.cz[ez] - D.cz[z];  // :137
-        const float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];     // :151
-        const float dot = ax * bx + ay * by + az * bz;
         const float na = sqrtf(ax * ax + ay * ay + az * az);
-        const float nb = sqrtf(bx * bx + by * by + bz * bz);
-        out = 1 + beta * (dot / (na * nb));   // :152-154 (0/0 = NaN on a duplicated seam coordinate, Q3)
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            int dx, dy, dz;
+            wa_edge_offset<NB>(k, dx, dy, dz);
+            const int32_t X = x + dx, Y = y + dy, Z = z + dz;
+            float out = 0.f;
+            if (X >= 0 && X < D.d.nx && Y >= 0 && Y < D.d.ny && Z >= 0 && Z < D.d.nz) {
+                const float bx = D.cx[X] - D.cx[x], by = D.cy[Y] - D.cy[y], bz = D.cz[Z] - D.cz[z];     // :151
+                const float dot = ax * bx + ay * by + az * bz;
+                const float nb = sqrtf(bx * bx + by * by + bz * bz);
+                out = 1 + beta * (dot / (na * nb));   // :152-154 (0/0 = NaN on a duplicated seam coordinate, Q3)
+            }
+            v[k] = out;
+        }
     }
-    D.heur[(int64_t)slot * D.pher_stride + t] = out;
+    wa_write_voxel_block<NB>(D.heur + (int64_t)slot * D.pher_stride, D.d.n, v, live);
 }
 
 // :247-249 -- colony in double then truncated, lambda double -> float, Q float
