@@ -16,6 +16,7 @@ struct WaAcsDev {
     int32_t *paths;                // [slot][max_colony][path_cap]  (solvers that hand stragglers over keep TWO such arrays and alternate by generation: see prev_paths)
     float *antL;                   // [slot][max_colony]
     int32_t *antLen;               // [slot][max_colony]
+    int32_t *antRep;               // [slot][max_colony]   1: the ant of the generation walked last ARRIVED ON THE REPLAY TRACK, i.e. its path is the best path it replayed, word for word (k_walk_dev; 0 from every other walk kernel): ranked ants of that kind are marked together (k_evap_rank_mark)
     int32_t *perm;                 // [slot][max_colony]   rank o-1 -> ant
     float *depA;                   // [slot][max_colony]   (lambda-o)*Q/L of rank o
     float *sortk;                  // [slot][2*max_colony] REF introsort scratch (key, tag records)
@@ -101,6 +102,12 @@ __device__ __forceinline__ void wa_mask_or(const WaMaskRef &m, int64_t e, int bi
 {
     if (m.w) atomicOr(&m.w[e], 1ULL << bit);
     else atomicOr(reinterpret_cast<unsigned int *>(m.b + (e & ~(int64_t)3)), (1u << bit) << (8 * (int)(e & 3)));
+}
+// several rank bits at once (ranks whose ants walked the same path: k_evap_rank_mark)
+__device__ __forceinline__ void wa_mask_or_bits(const WaMaskRef &m, int64_t e, unsigned long long bits)
+{
+    if (m.w) atomicOr(&m.w[e], bits);
+    else atomicOr(reinterpret_cast<unsigned int *>(m.b + (e & ~(int64_t)3)), ((unsigned int)bits & 0xffu) << (8 * (int)(e & 3)));
 }
 __device__ __forceinline__ unsigned long long wa_mask_get(const WaMaskRef &m, int64_t e) { return m.w ? m.w[e] : (unsigned long long)m.b[e]; }
 __device__ __forceinline__ void wa_mask_clear(const WaMaskRef &m, int64_t e)

@@ -313,6 +313,7 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 // Preconditions (checked by the host): DEV mode, colony <= WA_RANK_LDS, at most 64 depositing ranks.
 // split_log2: mark blocks per depositing rank = 1 << this (C3, 500 generations: 8 blocks per rank 21.6 k gen/s, 4 22.1 k, 2 21.9 k;
 // C5 with 224 searches per launch: 4 blocks 0.636 s, 2 0.622 s, 1 0.623 s) -- the host passes 2 or 1
+#define WA_LEN_OF(x) ((x) & 0x3fffffff)
 template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
                                                         float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period,
@@ -383,8 +384,9 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     for (int32_t a = tid; a < cmax; a += blockDim.x) {
         const float La = antL[a];
         const int32_t na = antLen[a];
+        const int32_t rep = D.antRep[(int64_t)slot * D.max_colony + a];
         s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
-        s_len[a] = na;
+        s_len[a] = na | ((rep & 1) << 30);        // (bit 30: the ant arrived on the replay track -- its path is the best path it replayed; WA_LEN_OF strips it)
     }
     if (colony > D.max_colony || colony > WA_RANK_LDS) {
         if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     if (mb == 0)
         for (int32_t a = tid; a < colony; a += blockDim.x) {
             myfin += (__uint_as_float((uint32_t)(s_keys[a] >> 32)) != INFINITY) ? 1 : 0;
-            mysteps += (unsigned long long)(s_len[a] - 1);
+            mysteps += (unsigned long long)(WA_LEN_OF(s_len[a]) - 1);
         }
     for (int32_t a = tid; a < colony; a += blockDim.x) {  // ascending (L, ant) by counting (:273-275, DEV tie rule)
         const unsigned long long ka = s_keys[a];
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
 #endif
         bool changed = false;
         if (iterAnt >= 0 && iterL < bestL) {
-            blen = s_len[iterAnt];
+            blen = WA_LEN_OF(s_len[iterAnt]);
             const int32_t *srcp = D.paths + ((int64_t)slot * D.max_colony + iterAnt) * D.path_cap;
             int32_t *dstp = D.bestpath + (int64_t)slot * D.path_cap;
             uint32_t *mark = D.bestmark + (int64_t)slot * D.d.n;
@@ -474,14 +476,32 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             wa_next_params(*ctl, R, (gen + 1) & 1);
         }
     }
-    // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o
+    // ---- mark: OR bit (o-1) into the rank mask of every directed edge of ranked ant o.
+    // Ranked ants that ARRIVED ON THE REPLAY TRACK walked the same path word for word (the best path as it stood during the walk): once a colony has
+    // converged that is nearly all of them, and marking each on its own puts n_dep atomics -- and, lazily evaporated, n_dep stamp exchanges -- on every
+    // edge of that one path (round 6: the lazy post-walk launch of a 32-search batch of 256-ant colonies was 46 % of the batch's kernel time).  The
+    // blocks of the LOWEST such rank mark for all of them (one OR of all their bits, one claim per voxel); the blocks of the others have nothing to do.
+    // Same masks, same stamps: the apply pass cannot tell.
+    __shared__ unsigned long long s_rep;
+    if (tid < 64) {
+        const bool r = tid < n_dep && ((s_len[s_perm[tid]] >> 30) & 1);
+        const unsigned long long G_ = __ballot(r);
+        if (tid == 0) s_rep = G_;
+    }
+    __syncthreads();
+    const unsigned long long G = s_rep;
     const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
     if (o > n_dep) return;
+    unsigned long long bits = 1ULL << bit;
+    if ((G >> bit) & 1ULL) {
+        if (bit != __ffsll((long long)G) - 1) return;
+        bits = G;
+    }
 #ifdef WA_TEST_KNOBS
     if (sweep_nt & 0x200) return;       // timing aid: the launch without the marks (nothing is deposited: the colony keeps exploring)
 #endif
     const int32_t a = s_perm[o - 1];
-    const int32_t len = s_len[a];
+    const int32_t len = WA_LEN_OF(s_len[a]);
     const int32_t *path = D.paths + ((int64_t)slot * D.max_colony + a) * D.path_cap;
     const WaMaskRef mask = wa_mask_of(D, slot);
     float *ph = dst_base + (int64_t)slot * D.pher_stride;
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         int32_t w = path[i];
         int32_t v = path[i - 1] & WaNbT<NB>::IDM;
         int64_t e = (int64_t)v * NB + ((uint32_t)w >> WaNbT<NB>::SHIFT);
-        wa_mask_or(mask, e, bit);
+        wa_mask_or_bits(mask, e, bits);
         if (SPARSE) {   // v receives a deposit: its record must be current (after this generation's evaporation) for the apply pass
             uint32_t *stamp = D.stamp + (int64_t)slot * D.d.n;
             const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;

@@ -692,6 +692,7 @@ __device__ __forceinline__ void wa_walk_one(const WaAcsDev &D, const WaRun &R, i
             if (lane == 0) {
                 D.antL[(int64_t)slot * D.max_colony + ant] = L;
                 D.antLen[(int64_t)slot * D.max_colony + ant] = st.len;
+                if (MODE == 1 && what == 2) D.antRep[(int64_t)slot * D.max_colony + ant] = 1;   // its path IS the best path it replayed (cleared at the top of this walk)
                 if (what == 2 && cut_n != 0x7fffffff) __hip_atomic_store(&sg.arr_len[WA_ARR_IDX & 255u], (uint32_t)st.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an arrival, for the straggler check (write-through: the checking ants sit on other XCDs)
             }
             return;
@@ -1109,6 +1110,9 @@ __global__ __launch_bounds__(64) void k_walk_dev(WaAcsDev D, WaRun R, int hash_l
     int32_t cut_n = 0x7fffffff;
     if (!SPARSE && ALPHA1 && (walk_flags & 32) && D.pool_n) cut_n = (int32_t)(c->lambda[gen & 1] - 1.f) + 1;
     if (cut_n < 1) cut_n = 1;
+    // the "arrived on the replay track" flag of this generation's ant: cleared here, set by wa_walk_one if it does (a resume block, above, finishes a
+    // PREVIOUS generation's ant and leaves the flag alone)
+    if (threadIdx.x == 0) D.antRep[(int64_t)slot * D.max_colony + ant] = 0;
     wa_walk_one<1, ALPHA1, SPARSE, WARM, REJ, DIRECT, T16>(D, R, slot, ant, c->start, c->end, antkey, lds, hash_log2, rs_unused, f, b, &D.ctl[slot].flags, rlen, bestL,
                                    c->clean[gen & 1], c->evap_base + (uint32_t)gen, walk_flags, c->best_ver, c->heur_slot, cut_n, nullptr, 0, gen);
 #ifdef WA_STRAG_TIME
