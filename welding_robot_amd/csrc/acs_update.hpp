@@ -317,8 +317,12 @@ __device__ __forceinline__ void wa_sweep_body(const float *src, float *dst, int6
 template <bool SPARSE, int NB>
 __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, const float *src_base,
                                                         float *dst_base, int32_t E, int32_t gen, int32_t MB, int32_t split_log2, int32_t lazy_period,
-                                                        int32_t sweep_nt)
+                                                        int32_t sweep_nt, int32_t rank_cap)
 {
+    // rank_cap: ants the rank arrays in (dynamic) LDS hold, 16 bytes each: the host passes WA_RANK_LDS for dense solvers -- the launch as it always was --
+    // and the solver's max_colony (rounded up to 64) for lazily evaporating ones, whose post-walk launch is all latency chains: a 33-KB block of a 256-ant
+    // colony kept four blocks per CU resident, a 4-KB one keeps eight (32 lazy 256-ant searches: 253 -> 283 k problem-generations/s, round 6)
+    extern __shared__ unsigned long long wa_rank_lds[];
     const int32_t slot = blockIdx.y, tid = threadIdx.x;
     // the MB rank/mark blocks come FIRST in the grid so that they are dispatched immediately and
     // their latency-bound work hides under the sweep blocks that follow
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     const float lambda = ctl->lambda[gen & 1], Q = ctl->Q[gen & 1];
     const float *antL = D.antL + (int64_t)slot * D.max_colony;
     const int32_t *antLen = D.antLen + (int64_t)slot * D.max_colony;
-    __shared__ unsigned long long s_keys[WA_RANK_LDS];
-    __shared__ int32_t s_perm[WA_RANK_LDS], s_len[WA_RANK_LDS];
+    unsigned long long *s_keys = wa_rank_lds;
+    int32_t *s_perm = reinterpret_cast<int32_t *>(wa_rank_lds + rank_cap), *s_len = s_perm + rank_cap;
     __shared__ int32_t s_ndep, s_fin;
     __shared__ unsigned long long s_steps;
     if (tid == 0) { s_ndep = 0; s_fin = 0; s_steps = 0; }
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     // the ants' results are requested for ALL max_colony ants before the control block says how many there are (inside the allocation;
     // entries beyond the colony are never looked at), and every ant's length goes to LDS with its key, so that the ranked ant's length is
     // an LDS read: control block + results -> path words -> marks, three levels instead of five.
-    const int32_t cmax = D.max_colony < WA_RANK_LDS ? D.max_colony : WA_RANK_LDS;
+    const int32_t cmax = D.max_colony < rank_cap ? D.max_colony : rank_cap;
     for (int32_t a = tid; a < cmax; a += blockDim.x) {
         const float La = antL[a];
         const int32_t na = antLen[a];
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
         s_keys[a] = ((unsigned long long)__float_as_uint(La) << 32) | (uint32_t)a;
         s_len[a] = na | ((rep & 1) << 30);        // (bit 30: the ant arrived on the replay track -- its path is the best path it replayed; WA_LEN_OF strips it)
     }
-    if (colony > D.max_colony || colony > WA_RANK_LDS) {
+    if (colony > D.max_colony || colony > rank_cap) {
         if (mb == 0 && tid == 0) atomicOr(&ctl->flags, WA_FLAG_COLONY_OVERFLOW);
         return;
     }
