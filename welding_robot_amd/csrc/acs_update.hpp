@@ -520,7 +520,14 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
             const uint32_t target = ctl->evap_base + (uint32_t)gen + 2u;
             const uint32_t old = atomicExch(&stamp[v], target);
             if (old == 0) {            // first deposit ever: v joins the dirty list, its record is written at the clean value
-                const int32_t idx = atomicAdd(&D.dcount[slot * 2 + 1], 1);
+                // (one atomic per WAVEFRONT on the list's cursor, not one per voxel: in a search's first generations nearly every marked voxel is new,
+                //  tens of thousands of increments of one address per search and launch)
+                const unsigned long long newm = __ballot(1);
+                const int lane_ = tid & 63, lead_ = __ffsll((long long)newm) - 1;
+                int32_t base_ = 0;
+                if (lane_ == lead_) base_ = atomicAdd(&D.dcount[slot * 2 + 1], (int32_t)__popcll(newm));
+                base_ = __shfl(base_, lead_, 64);
+                const int32_t idx = base_ + (int32_t)__popcll(newm & ((1ULL << lane_) - 1ULL));
                 D.dirty_list[(int64_t)slot * D.d.n + idx] = v;
 #pragma unroll
                 for (int k = 0; k < NB; k++) {   // stored = the init value: 0 stays 0 (out-of-bounds edge of initFromGridMap), p0 became clean_next
