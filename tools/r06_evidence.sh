@@ -36,6 +36,8 @@ done
 cd $R
 # 4. the saturated workloads as the final rule runs them
 python3 tools/pipeline_curve.py --P 1,2,4,8,16,32 --G 1,2 --kinds dense,lazy > $O/pipeline_curve.jsonl 2>&1
+python3 tools/pipeline_curve.py --P 8,16,32 --G 0 --kinds dense,lazy > $O/pipeline_curve_by_rule.jsonl 2>&1              # (--G 0: the library's rule -- three groups for lazy batches of big colonies)
+python3 tools/pipeline_curve.py --P 8,16,32 --G 0 --kinds dense,lazy --gens 500 > $O/pipeline_curve_500_by_rule.jsonl 2>&1
 python3 examples/plan_batch.py --grid 256 --points 64 --lazy > $O/plan_batch_c5.jsonl 2>&1
 python3 examples/plan_batch.py --grid 256 --points 64 --lazy >> $O/plan_batch_c5.jsonl 2>&1
 python3 tools/ref_time.py 500 > $O/ref_time.txt 2>&1
