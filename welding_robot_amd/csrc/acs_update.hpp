@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void k_rank(WaAcsDev D, WaRun R, int32_t gen)
         c.dep_bestL = bestL;
         c.n_dep = s_ndep;
         c.gen = gen + 1;
+        c.rep_mask = 0;   // (the plain loop marks and applies rank by rank)
         wa_next_params(c, R, (gen + 1) & 1);
         *ctl = c;
     }
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256) void k_evap_rank_mark(WaAcsDev D, WaRun R, con
     }
     __syncthreads();
     const unsigned long long G = s_rep;
+    if (mb == 0 && tid == 0) ctl->rep_mask = G;   // (for the apply pass: the blocks of the other replaying ranks have nothing to do there either)
     const int32_t bit = mb >> split_log2, bx = mb & ((1 << split_log2) - 1), o = bit + 1;
     if (o > n_dep) return;
     unsigned long long bits = 1ULL << bit;
@@ -596,7 +598,10 @@ __device__ __forceinline__ void wa_apply_body(const WaAcsDev &D, int32_t slot, i
     const int32_t n_dep = c->n_dep;
     const uint32_t ver = c->best_ver;
     const float lambda = c->dep_lambda, Q = c->dep_Q, bestL = c->dep_bestL;
+    const unsigned long long rep = c->rep_mask;
     if (o > n_dep) return;
+    // a rank whose ant replayed the best path, but not the lowest such rank: every edge of its path carries that lower rank's bit too, so it owns none
+    if (o <= 64 && ((rep >> (o - 1)) & 1ULL) && (o - 1) != __ffsll((long long)rep) - 1) return;
     if (tid < 64) s_dep[tid] = base + tid < n_dep ? dep_mine : 0.f;
     // level 2: the ranked ant's length and this thread's first path words
     const int32_t *path = D.paths + ((int64_t)slot * C + a) * D.path_cap;

@@ -58,6 +58,9 @@ struct WaSlotCtl {
     int32_t tabu_gen;       // generation in which the best path last changed: the replay-table rows of that generation rebuild besttabu[]
     int32_t heur_slot;      // whose heuristic field this search reads: searches of one wa_acs_begin with the same end point share one
     int32_t pad_;
+    // bit o-1: rank o of the generation just ranked belongs to an ant that arrived on the replay track (its path is the best path, word for word).
+    // The post-walk launch marks all of them through the lowest one; the apply pass skips the others (never an edge's lowest rank).  0 from k_rank
+    unsigned long long rep_mask;
 };
 
 // glibc TYPE_3 state as the kernels keep it: r[0..30], f index, b index
