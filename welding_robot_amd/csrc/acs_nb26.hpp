@@ -237,6 +237,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
     };
     int32_t r_node = 0;
     float r_L = 0.f;
+    if (MODE == 1 && !res_words && lane == 0) D.antRep[(int64_t)slot * D.max_colony + ant] = 0;   // (set again below if this ant arrives on the replay track)
     if (res_words) { r_node = res_len - 1; r_L = res_L; }
     else if (MODE == 1 && rlen > 1) {   // follow the best path while the ant's own draws take its edges
         const float *RT = D.rtab + (int64_t)slot * D.path_cap * WA_ROW26;
@@ -245,6 +246,7 @@ __device__ __forceinline__ void wa_walk_one26(const WaAcsDev &D, const WaRun &R,
         for (int32_t q = lane; q <= r_node; q += 64) path[q] = bpath[q];   // the walked prefix IS the best path's
         r_L = RT[(int64_t)r_node * WA_ROW26 + 28];                          // L on arrival at that node
         if (what != 3) {
+            if (what == 2 && lane == 0) D.antRep[(int64_t)slot * D.max_colony + ant] = 1;   // arrived on the replay track: its path is the best path (see k_evap_rank_mark)
             finish(what == 2 ? r_L : INFINITY, r_node + 1);
             return;
         }
