@@ -119,3 +119,25 @@ def test_pipelined_groups_across_run_boundaries_and_second_batch(ctx, case, chun
         assert_slot(res[2][q], res[1][q], ("second batch", q))
     s.close()
     dg.close()
+
+
+def test_groups_by_rule(ctx, case):
+    """the library's own choice (wa_acs_set_pipeline(0)): one group for a lone search, two as soon as there are two dense or four lazy searches, three for
+    six and more lazily evaporating searches with colonies of 128 ants and more (profiles/r06/groups_queues.txt); results are those of one stream"""
+    og, n = case
+    dg = api.Grid.from_occupancy(ctx, og.free, og.cx, og.cy, og.cz, og.precision, og.wall)
+    for lazy, ants, P, want in ((False, 48, 1, 1), (False, 48, 2, 2), (False, 128, 8, 2), (True, 48, 3, 1), (True, 48, 8, 2), (True, 128, 5, 2), (True, 128, 8, 3)):
+        s = api.AcsSolver(ctx, dg, P, ants, lazy=lazy)
+        p = api.default_params(max_iteration=4, predict=132.0, fixed_colony=ants, rng_mode=api.RNG_DEV, seed=11)
+        hist = {}
+        for groups in (0, 1):
+            s.set_pipeline(groups)
+            s.init_pheromone(1.0)
+            s.solve(p, [0] * P, [n - 1] * P, streams=list(range(20, 20 + P)))
+            if groups == 0:
+                assert s.pipeline_groups() == want, (lazy, ants, P, s.pipeline_groups())
+            hist[groups] = [slot_state(s, q, 4) for q in range(P)]
+        for q in range(P):
+            assert_slot(hist[0][q], hist[1][q], ("by rule", lazy, ants, P, q))
+        s.close()
+    dg.close()
